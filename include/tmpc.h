@@ -1,0 +1,166 @@
+/*
+ * tmpc.h -- C ABI of the MI355X tube-tracking-MPC solve engine (libtmpc_hip.so).
+ *
+ * Drop-in boundary for ONE hot path of
+ * EricssonResearch/Robust-Tracking-MPC-over-Lossy-Networks: the per-timestep QP of
+ * TubeTrackingMPC / ExtendedTubeTrackingMPC, batched over independent
+ * Monte-Carlo trajectories.  Each entry point names the reference interface it
+ * replaces (paths relative to the reference's src/LinearMPCOverNetworks/).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every matrix is float64, row-major, dense;
+ *   - the caller owns all buffers passed in; the library owns the opaque handle,
+ *     its device copies of the problem, its scratch and its HIP stream;
+ *   - every function returns 0 on success and a negative TMPC_E_* code otherwise;
+ *     tmpc_last_error() gives the message; no C++ exception crosses the boundary;
+ *   - a handle is not thread-safe; use one handle per host thread / per GPU.
+ */
+#ifndef TMPC_H
+#define TMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TMPC_ABI_VERSION 1
+
+/* error codes (function return values) */
+#define TMPC_OK            0
+#define TMPC_E_INVALID    -1   /* bad argument / inconsistent problem description      */
+#define TMPC_E_UNSUPPORTED -2  /* problem size outside what the compiled kernels cover */
+#define TMPC_E_DEVICE     -3   /* HIP runtime error                                     */
+#define TMPC_E_NOMEM      -4
+
+/* per-instance solver status (status[] output), mirroring what the reference reads
+ * from cvxpy: "optimal" / "optimal_inaccurate" / "infeasible" / failure -> None
+ * (TubeTrackingMPC.py:185-194) */
+#define TMPC_STATUS_OPTIMAL     0
+#define TMPC_STATUS_MAX_ITER    1   /* iteration cap hit; last iterate returned          */
+#define TMPC_STATUS_INFEASIBLE  2   /* no x satisfies the constraints for this (x_k)     */
+#define TMPC_STATUS_NUMERICAL   3
+
+/*
+ * Problem description: everything `TubeTrackingMPC.generate_optimization_problem`
+ * (TubeTrackingMPC.py:104-156) and, when `extended` is set,
+ * `ExtendedTubeTrackingMPC.generate_optimization_problem_when_packet_received`
+ * (TubeTrackingMPC.py:253-299) close over.
+ *
+ *   model     x+ = A x + B u                      A: nx*nx   B: nx*nu     (RegulatorMPC.py:13-14)
+ *   weights   Q: nx*nx  R: nu*nu                                          (RegulatorMPC.py:24-25)
+ *             P: nx*nx  terminal weight                                   (TubeRegulatorMPC.py:23)
+ *             T: nx*nx  steady-state offset weight = 10 P                 (TubeTrackingMPC.py:27)
+ *   gains     K: nu*nx steady-state LQR gain, K_anc: nu*nx ancillary gain (TubeTrackingMPC.py:229-240)
+ *   sets      {Hx x <= hx}   rx rows, tightened state set  Xc            (TubeTrackingMPC.py:112)
+ *             {Hu u <= hu}   ru rows, tightened input set  Uc            (TubeTrackingMPC.py:110)
+ *             {HT [x_N; x_bar; u_bar] <= hT}  rT rows, terminal set Xf in R^(2nx+nu) (TubeTrackingMPC.py:114,149)
+ *             {HZ e <= hZ}   rZ rows, mRPI set Z; used iff fixed_x0 == 0  (TubeTrackingMPC.py:130-132)
+ *             {HZW e <= hZW} rZW rows, Z (-) W; used iff extended != 0    (TubeTrackingMPC.py:266-278)
+ *
+ * fixed_x0 : 1 -> x_0 == x_k (TubeTrackingMPC.py:127); 0 -> HZ (x_k - x_0) <= hZ (TubeTrackingMPC.py:132).
+ * extended : 1 -> a second QP ("variant 1") is prepared for instances whose
+ *            previous plant packet arrived (gamma_t == 1, TubeTrackingMPC.py:312).
+ * literal_terminal_row : 1 (default) reproduces TubeTrackingMPC.py:293 literally: in
+ *            variant 1 the terminal inequality is written on x_mpc[:,N] and u_bar of the
+ *            *base* problem, i.e. on free auxiliary variables; 0 uses the variant's own
+ *            x_N and u_bar instead.
+ * tol      : relative primal-residual / duality-gap level at which the interior-point
+ *            phase hands over to the exact active-set refinement; <= 0 selects the
+ *            default 1e-7 (tightened by 1e-2 and retried whenever the refinement
+ *            cannot certify its active set).
+ * max_iter : interior-point iteration cap; <= 0 selects the default 60.
+ */
+typedef struct tmpc_problem {
+    int32_t nx, nu, N;
+    int32_t rx, ru, rT, rZ, rZW;
+    int32_t fixed_x0, extended, literal_terminal_row;
+    int32_t max_iter;
+    double  tol;
+    const double *A, *B, *Q, *R, *P, *T, *K, *K_anc;
+    const double *Hx, *hx, *Hu, *hu, *HT, *hT, *HZ, *hZ, *HZW, *hZW;
+} tmpc_problem;
+
+typedef struct tmpc_handle tmpc_handle;
+
+/* ABI version of the loaded library (compare with TMPC_ABI_VERSION). */
+int tmpc_abi_version(void);
+
+/* Last error message of `h`, or of the last failed tmpc_create when h == NULL. */
+const char *tmpc_last_error(const tmpc_handle *h);
+
+/*
+ * Replaces generate_optimization_problem(fixed_initial_state)
+ * (TubeTrackingMPC.py:104-156) [+ :253-299 when p->extended]: condenses the QP(s)
+ * once, uploads them to HIP device `device`, allocates scratch.
+ */
+int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out);
+
+void tmpc_destroy(tmpc_handle *h);
+
+/*
+ * Replaces solve_optimization_problem(x_init, ref[, gamma_t])
+ * (TubeTrackingMPC.py:170-194, :307-349) for B independent instances.
+ *
+ *   in   x_k     B*nx     state estimate handed to the controller (x_init)
+ *        ref     B*nx     reference state                          (ref)
+ *        variant B or NULL  0 = base problem, 1 = packet-received problem (gamma_t)
+ *   out  u_nom   B*N*nu   nominal inputs u_0..u_{N-1}   (reference returns its transpose, nu*N)
+ *        x_nom0  B*nx     x_nom[:,0]                     (TubeTrackingMPC.py:364)
+ *        xu_ss   B*(nx+nu) [x_bar | u_bar]               (TubeTrackingMPC.py:191-192)
+ *        x_nom   B*(N+1)*nx or NULL  full nominal state trajectory
+ *        status  B        TMPC_STATUS_*
+ *        iters   B        interior-point iterations used
+ *
+ * All pointers are HOST pointers; the call copies in, launches, copies out and
+ * returns when the results are in place.  Outputs of instances with
+ * status >= TMPC_STATUS_INFEASIBLE are NaN (the reference returns None).
+ */
+int tmpc_solve_batch(tmpc_handle *h, int64_t B,
+                     const double *x_k, const double *ref, const uint8_t *variant,
+                     double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
+                     int32_t *status, int32_t *iters);
+
+/*
+ * Same, with every pointer a DEVICE pointer on the handle's device (e.g. a torch
+ * tensor's data_ptr()).  The kernels are enqueued on the handle's stream and the
+ * call returns without synchronising; use tmpc_synchronize() or
+ * tmpc_last_kernel_ms().
+ */
+int tmpc_solve_batch_device(tmpc_handle *h, int64_t B,
+                            const double *x_k, const double *ref, const uint8_t *variant,
+                            double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
+                            int32_t *status, int32_t *iters);
+
+/* Block until everything enqueued on the handle's stream has finished. */
+int tmpc_synchronize(tmpc_handle *h);
+
+/*
+ * Device time of the solve kernel(s) of the most recent tmpc_solve_batch[_device]
+ * call, from HIP events recorded on the handle's stream around the launch
+ * (synchronises the stream).  This is what bench.py reports as the kernel's
+ * launch duration.
+ */
+int tmpc_last_kernel_ms(tmpc_handle *h, float *ms);
+
+/*
+ * Introspection for DESIGN.md / bench.py's roofline accounting: dimensions of the
+ * condensed QP of `variant` as the kernels see it.
+ *   nv   decision variables after condensing
+ *   nc   inequality rows kept (rows that cannot bind for any x_k are dropped)
+ *   npar rows that depend on x_k only (checked once per instance, not iterated on)
+ */
+int tmpc_get_dims(const tmpc_handle *h, int variant, int32_t *nv, int32_t *nc, int32_t *npar);
+
+/*
+ * Copies the condensed, unscaled QP data of `variant` to caller buffers (any may be
+ * NULL): the QP is  min 1/2 z'Hz + (F1 x_k + F2 ref)'z  s.t.  G z <= g0 + E x_k.
+ *   H nv*nv, F1 nv*nx, F2 nv*nx, G nc*nv, g0 nc, E nc*nx.   Used by the tests.
+ */
+int tmpc_get_condensed(const tmpc_handle *h, int variant,
+                       double *H, double *F1, double *F2, double *G, double *g0, double *E);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TMPC_H */

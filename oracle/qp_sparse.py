@@ -1,0 +1,187 @@
+"""ORACLE (test infrastructure, not product code): the tube-tracking QP in the
+reference's own, un-condensed variables, as plain numpy.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this file.  PARITY UNPINNED: the reference repository holds no golden vectors or
+known-answer tests for the QP solution and its solver stack (cvxpy -> Clarabel)
+is not installable here, so this restatement is pinned only by (i) a KKT
+certificate of every solution it is used to check and (ii) an independent
+scipy cross-check at small sizes (tests/test_oracle.py).
+
+`build_sparse_qp` follows `TubeTrackingMPC.generate_optimization_problem`
+(reference src/LinearMPCOverNetworks/TubeTrackingMPC.py:104-156) line by line:
+
+    variables   x_mpc (nx,N+1), u_mpc (nu,N), x_bar (nx), u_bar (nu)      :117-120
+    initial     x_init - x_0 == 0            (fixed_initial_state)         :127
+                Hz (x_init - x_0) <= hz      (otherwise)                   :132
+    stage i<N   cost (x_i-x_bar)'Q(x_i-x_bar) + (u_i-u_bar)'R(u_i-u_bar)   :136
+                x_{i+1} == A x_i + B u_i                                    :138
+                Hx x_i <= hx ,  Hu u_i <= hu                                :139-140
+    terminal    cost (x_N-x_bar)'P(x_N-x_bar) + (x_bar-ref)'T(x_bar-ref)   :143-144
+                (A-I) x_bar + B u_bar == 0                                  :147
+                HT[:, :nx] x_N + HT[:, nx:2nx] x_bar + HT[:, 2nx:] u_bar <= hT   :149
+
+and, for the packet-received problem of `ExtendedTubeTrackingMPC`
+(:253-299), the same with Z (-) W in the initial constraint (:266-278) and the
+terminal row written literally as in :293, i.e. on `x_mpc[:, N]` and `u_bar` of
+the *base* problem, which are free auxiliary variables of this problem.
+
+The QP is returned in the standard form
+        min 1/2 v'Pv + q'v + c0   s.t.  Aeq v = beq,  G v <= h.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Layout:
+    """Index bookkeeping for v = [x_0..x_N | u_0..u_{N-1} | x_bar | u_bar | (x_aux | u_aux)]."""
+
+    def __init__(self, nx, nu, N, aux=False):
+        self.nx, self.nu, self.N, self.aux = nx, nu, N, aux
+        self.ox = 0
+        self.ou = nx * (N + 1)
+        self.oxb = self.ou + nu * N
+        self.oub = self.oxb + nx
+        self.oxa = self.oub + nu
+        self.oua = self.oxa + nx
+        self.nvar = self.oub + nu + ((nx + nu) if aux else 0)
+
+    def x(self, i):
+        return slice(self.ox + i * self.nx, self.ox + (i + 1) * self.nx)
+
+    def u(self, i):
+        return slice(self.ou + i * self.nu, self.ou + (i + 1) * self.nu)
+
+    @property
+    def xbar(self):
+        return slice(self.oxb, self.oxb + self.nx)
+
+    @property
+    def ubar(self):
+        return slice(self.oub, self.oub + self.nu)
+
+    @property
+    def xaux(self):
+        return slice(self.oxa, self.oxa + self.nx)
+
+    @property
+    def uaux(self):
+        return slice(self.oua, self.oua + self.nu)
+
+
+def build_sparse_qp(p: dict, x_k, ref, variant: int = 0):
+    """p: the problem dict of TubeTrackingMPC._problem_dict().  variant 1 = the
+    packet-received problem (needs p['HZW'], p['hZW'])."""
+    nx, nu, N = int(p["nx"]), int(p["nu"]), int(p["N"])
+    A, B, Q, R, Pm, T = (np.asarray(p[k], dtype=np.float64) for k in ("A", "B", "Q", "R", "P", "T"))
+    Hx, hx, Hu, hu, HT, hT = (np.asarray(p[k], dtype=np.float64) for k in ("Hx", "hx", "Hu", "hu", "HT", "hT"))
+    x_k = np.asarray(x_k, dtype=np.float64).reshape(nx)
+    ref = np.asarray(ref, dtype=np.float64).reshape(nx)
+    received = variant == 1
+    L = Layout(nx, nu, N, aux=received)
+    nv = L.nvar
+
+    def sel(s):
+        E = np.zeros((s.stop - s.start, nv))
+        E[np.arange(s.stop - s.start), np.arange(s.start, s.stop)] = 1.0
+        return E
+
+    Pq = np.zeros((nv, nv))
+    q = np.zeros(nv)
+    c0 = 0.0
+    for i in range(N):
+        Dx = sel(L.x(i)) - sel(L.xbar)
+        Du = sel(L.u(i)) - sel(L.ubar)
+        Pq += 2 * (Dx.T @ Q @ Dx + Du.T @ R @ Du)
+    Dx = sel(L.x(N)) - sel(L.xbar)
+    Pq += 2 * Dx.T @ Pm @ Dx
+    Eb = sel(L.xbar)
+    Pq += 2 * Eb.T @ T @ Eb
+    q += -2 * Eb.T @ (T @ ref)
+    c0 += float(ref @ T @ ref)
+
+    Aeq, beq, G, h = [], [], [], []
+    if received:
+        HZ, hZ = np.asarray(p["HZW"], dtype=np.float64), np.asarray(p["hZW"], dtype=np.float64)
+        G.append(-HZ @ sel(L.x(0)))
+        h.append(hZ - HZ @ x_k)
+    elif int(p["fixed_x0"]):
+        Aeq.append(sel(L.x(0)))
+        beq.append(x_k)
+    else:
+        HZ, hZ = np.asarray(p["HZ"], dtype=np.float64), np.asarray(p["hZ"], dtype=np.float64)
+        G.append(-HZ @ sel(L.x(0)))
+        h.append(hZ - HZ @ x_k)
+    for i in range(N):
+        Aeq.append(sel(L.x(i + 1)) - A @ sel(L.x(i)) - B @ sel(L.u(i)))
+        beq.append(np.zeros(nx))
+        G.append(Hx @ sel(L.x(i)))
+        h.append(hx)
+        G.append(Hu @ sel(L.u(i)))
+        h.append(hu)
+    Aeq.append((A - np.eye(nx)) @ sel(L.xbar) + B @ sel(L.ubar))
+    beq.append(np.zeros(nx))
+    if received:
+        G.append(HT[:, :nx] @ sel(L.xaux) + HT[:, nx:2 * nx] @ sel(L.xbar) + HT[:, 2 * nx:] @ sel(L.uaux))
+    else:
+        G.append(HT[:, :nx] @ sel(L.x(N)) + HT[:, nx:2 * nx] @ sel(L.xbar) + HT[:, 2 * nx:] @ sel(L.ubar))
+    h.append(hT)
+    return dict(P=Pq, q=q, c0=c0, A=np.vstack(Aeq), b=np.concatenate(beq),
+                G=np.vstack(G), h=np.concatenate(h), layout=L)
+
+
+def unpack(qp: dict, v: np.ndarray):
+    """-> x_nom (N+1,nx), u_nom (N,nu), x_ss (nx), u_ss (nu)."""
+    L = qp["layout"]
+    x = v[L.ox:L.ou].reshape(L.N + 1, L.nx)
+    u = v[L.ou:L.oxb].reshape(L.N, L.nu)
+    return x, u, v[L.xbar], v[L.ubar]
+
+
+def pack(qp: dict, x_nom, u_nom, x_ss, u_ss):
+    L = qp["layout"]
+    v = np.zeros(L.nvar)
+    v[L.ox:L.ou] = np.asarray(x_nom).reshape(-1)
+    v[L.ou:L.oxb] = np.asarray(u_nom).reshape(-1)
+    v[L.xbar] = x_ss
+    v[L.ubar] = u_ss
+    return v
+
+
+def objective(qp: dict, v: np.ndarray) -> float:
+    return float(0.5 * v @ qp["P"] @ v + qp["q"] @ v + qp["c0"])
+
+
+def kkt_certificate(qp: dict, v: np.ndarray, act_tol: float = 1e-7):
+    """Independent optimality certificate for a candidate primal point `v`.
+
+    Identifies the active inequalities, recovers multipliers by a bounded
+    least-squares fit of the stationarity equation, and reports
+
+        r_stat  = || P v + q + A' y + G_act' lam ||_inf   (relative to max(1,|q|))
+        r_eq    = || A v - b ||_inf
+        r_ineq  = max(G v - h, 0)
+        min_lam = smallest active multiplier (>= 0 required)
+
+    Small values of the first three with min_lam >= 0 prove that `v` is the
+    (unique, strictly convex case) minimiser, whichever solver produced it."""
+    from scipy.optimize import lsq_linear
+    P, q, A, b, G, h = (qp[k] for k in ("P", "q", "A", "b", "G", "h"))
+    slack = h - G @ v
+    scale = np.maximum(1.0, np.abs(h))
+    act = np.flatnonzero(slack <= act_tol * scale)
+    g = P @ v + q
+    Mx = np.c_[A.T, G[act].T]
+    lb = np.r_[np.full(A.shape[0], -np.inf), np.zeros(len(act))]
+    colscale = np.maximum(np.linalg.norm(Mx, axis=0), 1e-300)
+    res = lsq_linear(Mx / colscale, -g, bounds=(lb, np.full(Mx.shape[1], np.inf)),
+                     method="bvls", tol=1e-15, max_iter=10 * Mx.shape[1] + 100)
+    mult = res.x / colscale
+    r = g + Mx @ mult
+    lam = mult[A.shape[0]:]
+    return dict(r_stat=float(np.max(np.abs(r)) / max(1.0, np.max(np.abs(q)))),
+                r_eq=float(np.max(np.abs(A @ v - b))) if A.size else 0.0,
+                r_ineq=float(max(0.0, np.max(-slack))),
+                min_lam=float(lam.min()) if lam.size else 0.0,
+                n_active=int(len(act)), active=act, lam=lam)

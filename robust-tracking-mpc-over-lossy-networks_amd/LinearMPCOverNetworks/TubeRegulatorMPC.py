@@ -1,0 +1,84 @@
+"""Parent pieces of the tube-tracking controller that the hot path consumes.
+
+Only what `TubeTrackingMPC` inherits is provided: the constructor chain
+(reference `RegulatorMPC.py:11-43`, `TubeRegulatorMPC.py:16-24`) that produces
+`K`, `P`, `Acl`, and the mRPI driver with its s_max x10 retry
+(`TubeRegulatorMPC.py:26-78`).  The regulator QPs of those two reference classes
+are different controllers and are not part of the accelerated path.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import utils_polytope as up
+from .control_lite import dlqr, dlyap
+from .polytope_lite import as_polytope, reduce
+
+
+class RegulatorMPC:
+    """State container + constraint setters (reference RegulatorMPC.py:11-43, :93)."""
+
+    def __init__(self, A, B, Q, R, N: int) -> None:
+        self._A = np.array(A, dtype=np.float64)
+        self._B = np.array(B, dtype=np.float64)
+        self._N = int(N)
+        self._nx = self._A.shape[1]
+        self._nu = self._B.shape[1]
+        self._Q = np.array(Q, dtype=np.float64)
+        self._R = np.atleast_2d(np.array(R, dtype=np.float64))
+        self._X = None
+        self._U = None
+        # the reference stores cp.CLARABEL here (RegulatorMPC.py:31); this build has
+        # exactly one back-end, the HIP library
+        self._solver = "hip"
+
+    def set_state_constraints(self, X) -> None:
+        self._X = as_polytope(X)
+
+    def set_input_constraints(self, U) -> None:
+        self._U = as_polytope(U)
+
+    def set_solver(self, solver) -> None:
+        """Reference RegulatorMPC.py:93-94.  Only the HIP back-end exists here."""
+        if str(solver).lower() not in ("hip", "clarabel"):
+            raise ValueError("this build solves on the MI355X only (solver='hip')")
+        self._solver = "hip"
+
+
+class TubeRegulatorMPC(RegulatorMPC):
+    def __init__(self, A, B, Q, R, N: int) -> None:
+        super().__init__(A, B, Q, R, N)
+        K, _, _ = dlqr(self._A, self._B, self._Q, self._R)      # TubeRegulatorMPC.py:19
+        self._K = K
+        Q_lyap = self._Q + K.T @ self._R @ K
+        Q_lyap = (Q_lyap + Q_lyap.T) / 2
+        self._Acl = self._A - self._B @ K
+        # python-control convention  Acl P Acl^T - P + Q_lyap = 0  (TubeRegulatorMPC.py:23)
+        self._P = dlyap(self._Acl, Q_lyap)
+        self._Z = None
+
+    def determine_mRPI(self, W, eps_var: float = 1.9e-5, Acl=None, rpi_method: int = 0, K=None):
+        """Reference TubeRegulatorMPC.py:26-78."""
+        if K is None:
+            K = self._K
+        if Acl is None:
+            Acl = self._Acl
+        if np.max(np.abs(np.linalg.eigvals(Acl))) >= 1:
+            print("The matrix Acl is not stable, such that the algorithm will never converge. \n"
+                  " Therefore, None is returned")
+            return None
+        s_max = 200
+        while True:
+            if rpi_method == 1:
+                Fs_temp, status = up.calculate_RPI(Acl, W, self._X, self._U, K, eps_var=eps_var, s_max=s_max)
+            else:
+                if rpi_method != 0:
+                    print("The method chosen to determine the RPI does not exists, so we use the default method 0")
+                Fs_temp, status = up.calculate_minimal_robust_positively_invariant_set(
+                    Acl, W=W, eps_var=eps_var, s_max=s_max)
+            if status == 0:
+                break
+            print(f"RPI not determined in {s_max} steps. Increasing s_max to 10*s_max = {10 * s_max}")
+            s_max *= 10
+        self._Z = reduce(Fs_temp)
+        return self._Z

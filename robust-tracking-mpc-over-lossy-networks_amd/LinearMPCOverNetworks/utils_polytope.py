@@ -1,0 +1,286 @@
+"""Host-side set algebra for the offline stage of the tube-tracking MPC.
+
+Restates, on top of `polytope_lite` + scipy only, the set operations the
+reference performs once per model before the first QP is solved
+(reference `utils_polytope.py`):
+
+    support                       utils_polytope.py:12-23
+    pont_diff                     utils_polytope.py:25-38
+    mink_sum / convex hull        utils_polytope.py:40-113, 160-178
+    scale                         utils_polytope.py:115-158
+    Rakovic eps-mRPI              utils_polytope.py:180-245
+    Gilbert-Tan max. output-admissible set   utils_polytope.py:247-268
+    Darup-Teichrib RPI            utils_polytope.py:270-414
+
+The outputs (Z, Xc, Uc, Xf) are the (H, h) blocks the HIP solve kernels
+consume.  Two things are done differently from the reference, neither of which
+changes the resulting sets:
+
+* supports over axis-aligned boxes are evaluated in closed form instead of by
+  an LP (the cartpole Darup recursion needs several thousand of them);
+* the linear image `-K Z` needed by the tightening step
+  (TubeTrackingMPC.py:98-101) is never vertex-enumerated; its support is taken
+  as h_{MZ}(a) = h_Z(M^T a).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import linprog
+from scipy.spatial import ConvexHull, HalfspaceIntersection
+
+from .polytope_lite import (ABS_TOL, Polytope, _lp_max, as_polytope, box_bounds,
+                            reduce)
+
+
+class LinearImage:
+    """The set {M x | x in P}, known only through its support function."""
+
+    def __init__(self, P: Polytope, M: np.ndarray):
+        self.P = as_polytope(P)
+        self.M = np.atleast_2d(np.asarray(M, dtype=np.float64))
+
+    @property
+    def dim(self) -> int:
+        return self.M.shape[0]
+
+
+def support(poly, x) -> float:
+    """h_P(x) = max_{y in P} x^T y  (utils_polytope.py:12-23)."""
+    x = np.asarray(x, dtype=np.float64).reshape(-1)
+    if isinstance(poly, LinearImage):
+        return support(poly.P, poly.M.T @ x)
+    poly = as_polytope(poly)
+    bb = getattr(poly, "_box", False)
+    if bb is False:
+        bb = box_bounds(poly)
+        poly._box = bb
+    if bb is not None:
+        lo, hi = bb
+        return float(np.sum(np.where(x >= 0, x * hi, x * lo)))
+    val, st = _lp_max(x, poly.A, poly.b)
+    if st != 0:
+        print(f"Status of the support linear program: {st}")
+    return float(val)
+
+
+def pont_diff(poly1, poly2) -> Polytope:
+    """P1 (-) P2 = {x | x + y in P1 for all y in P2}: same rows as P1, offsets
+    reduced by the support of P2 along each row (utils_polytope.py:25-38)."""
+    poly1 = as_polytope(poly1)
+    b = poly1.b.copy()
+    for i, a in enumerate(poly1.A):
+        b[i] -= support(poly2, a)
+    return Polytope(poly1.A.copy(), b)
+
+
+def extreme(poly) -> np.ndarray:
+    """Vertices (rows) of a bounded full-dimensional polytope."""
+    poly = as_polytope(poly)
+    if poly.vertices is not None:
+        return poly.vertices.copy()
+    n = poly.dim
+    if n == 1:
+        hi = min(bi / a[0] for a, bi in zip(poly.A, poly.b) if a[0] > 0)
+        lo = max(bi / a[0] for a, bi in zip(poly.A, poly.b) if a[0] < 0)
+        return np.array([[lo], [hi]])
+    # Chebyshev centre as the strictly interior point qhull needs
+    nrm = np.linalg.norm(poly.A, axis=1)
+    res = linprog(np.r_[np.zeros(n), -1.0], A_ub=np.c_[poly.A, nrm], b_ub=poly.b,
+                  bounds=[(None, None)] * n + [(0, None)], method="highs")
+    if res.status != 0 or res.x[-1] <= 0:
+        raise ValueError("polytope is empty or not full dimensional")
+    hs = HalfspaceIntersection(np.c_[poly.A, -poly.b], res.x[:n])
+    V = hs.intersections
+    V = V[ConvexHull(V).vertices] if V.shape[0] > n + 1 else V
+    poly.vertices = V
+    return V.copy()
+
+
+def determine_convex_hull(vertices: np.ndarray) -> Polytope:
+    """H-representation of conv(vertices), one vertex per row (utils_polytope.py:160-178)."""
+    vertices = np.asarray(vertices, dtype=np.float64)
+    if vertices.shape[1] == 1:
+        lo, hi = vertices.min(), vertices.max()
+        return Polytope([[1.0], [-1.0]], [hi, -lo], vertices=np.array([[lo], [hi]]))
+    hull = ConvexHull(vertices)
+    eq = hull.equations
+    # qhull returns one facet per simplex; merge coplanar duplicates
+    _, idx = np.unique(np.round(eq, 10), axis=0, return_index=True)
+    eq = eq[np.sort(idx)]
+    return Polytope(eq[:, :-1], -eq[:, -1], vertices=vertices[hull.vertices])
+
+
+def mink_sum(poly1, poly2) -> Polytope:
+    """P1 (+) P2 for a polytope, a point or a vertex list (utils_polytope.py:40-113)."""
+    poly1 = as_polytope(poly1)
+    if isinstance(poly2, np.ndarray) and poly2.ndim == 1:
+        return Polytope(poly1.A, poly1.b + poly1.A @ poly2)
+    V1 = extreme(poly1)
+    V2 = poly2 if isinstance(poly2, np.ndarray) else extreme(poly2)
+    sums = (V1[:, None, :] + V2[None, :, :]).reshape(-1, V1.shape[1])
+    return determine_convex_hull(sums)
+
+
+def scale(poly, scaling_variable):
+    """s*P for a scalar, M*P for a matrix (utils_polytope.py:115-158).
+
+    A matrix image with a one-dimensional range is returned as an interval;
+    otherwise it is returned as a `LinearImage`, which `support`/`pont_diff`
+    accept wherever the reference passes the vertex-enumerated polytope."""
+    poly = as_polytope(poly)
+    sv = np.asarray(scaling_variable, dtype=np.float64)
+    if np.squeeze(sv).ndim == 0:   # the reference treats a 1x1 array as a scalar too
+        s = float(np.squeeze(sv))
+        if s == 1:
+            return poly.copy()
+        if s == 0:
+            n = poly.dim
+            return Polytope(np.r_[np.eye(n), -np.eye(n)], np.zeros(2 * n))
+        if s > 0:
+            return Polytope(poly.A, s * poly.b,
+                            None if poly.vertices is None else s * poly.vertices)
+        return Polytope(poly.A / s, poly.b)
+    M = np.atleast_2d(sv)
+    if M.shape[0] == 1:
+        hi = support(poly, M[0])
+        lo = -support(poly, -M[0])
+        return Polytope([[1.0], [-1.0]], [hi, -lo])
+    if poly.vertices is not None or poly.dim <= 3:
+        return determine_convex_hull(extreme(poly) @ M.T)
+    return LinearImage(poly, M)
+
+
+def calculate_minimal_robust_positively_invariant_set(A, W, eps_var: float = 1.9e-5, s_max: int = 20):
+    """Rakovic et al. eps-outer approximation of the mRPI set of x+ = A x + w
+    (utils_polytope.py:180-245).  Returns (F_s / (1 - alpha), status)."""
+    A = np.asarray(A, dtype=np.float64)
+    W = as_polytope(W)
+    if A.shape[0] != A.shape[1]:
+        print("A needs to be a square matrix. Returning None")
+        return None
+    if np.any(W.b <= 0):
+        print("The polytope W does not contain the origin. Therefore, we return None")
+        return None
+    F, g = W.A, W.b
+    nx = A.shape[0]
+    A_pwr = [np.linalg.matrix_power(A, i) for i in range(s_max)]
+    M_pos = np.zeros(nx)
+    M_neg = np.zeros(nx)
+    status, s, alpha = -1, 0, None
+    while s < s_max - 1:
+        s += 1
+        alpha = max(support(W, A_pwr[s].T @ F[i]) / g[i] for i in range(F.shape[0]))
+        for j in range(nx):
+            M_pos[j] += support(W, A_pwr[s - 1][j])
+            M_neg[j] += support(W, -A_pwr[s - 1][j])
+        M_s = max(M_pos.max(), M_neg.max())
+        if alpha <= eps_var / (eps_var + M_s):
+            status = 0
+            break
+    if status != 0:
+        print(f"In the RPI calculation, we reached the iteration maximum {s_max} without converging!")
+        return None, status
+    VW = extreme(W)
+    Fs = Polytope(W.A, W.b, vertices=VW)
+    for i in range(1, s):
+        Fs = mink_sum(Fs, VW @ A_pwr[i].T)
+    return scale(Fs, 1.0 / (1.0 - alpha)), status
+
+
+def calculate_maximum_admissible_output_set(A, X, abs_tol: float = ABS_TOL, t_max: int = 100000,
+                                            verbose: bool = True) -> Polytope:
+    """Gilbert-Tan Algorithm 3.1: O_inf of x+ = A x subject to x(k) in X for all k
+    (utils_polytope.py:247-268).
+
+    The reference builds O_{t+1} = O_t /\\ {G A^{t+1} x <= f} and stops when
+    O_{t+1} == O_t.  Equality holds exactly when every new row is redundant for
+    O_t, which is what is tested here (one LP per new row); rows are appended
+    only when they cut, and the final set is reduced once."""
+    A = np.asarray(A, dtype=np.float64)
+    X = as_polytope(X)
+    G, f = X.A, X.b
+    H, h = G.copy(), f.copy()
+    At = np.eye(A.shape[0])
+    t = 0
+    while t < t_max:
+        At = At @ A
+        Gn = G @ At
+        added = False
+        newH, newh = [], []
+        for a, bi in zip(Gn, f):
+            if np.linalg.norm(a) < 1e-14:
+                continue
+            val, st = _lp_max(a, H, h)
+            if st != 0 or val > bi + abs_tol:
+                newH.append(a)
+                newh.append(bi)
+                added = True
+        if not added:
+            if verbose:
+                print(f"Admissible set calculation has converged at t = {t}")
+            break
+        H = np.r_[H, np.array(newH)]
+        h = np.r_[h, np.array(newh)]
+        t += 1
+    return reduce(Polytope(H, h), abs_tol)
+
+
+def calculate_RPI(A, W, X, U, K, eps_var: float = 1e-4, s_max: int = 20,
+                  return_container: bool = False, verbose: bool = True):
+    """Darup-Teichrib RPI approximation (utils_polytope.py:270-414).
+
+    k* is the first k with (9a) (1+eps) h_W((Hw A^k)_i) <= eps hw_i for all i and
+    (9b) (1+eps) sum_{j<k} h_W((Hd A^j)_l) <= hd_l for all l, Hd = [Hx; -Hu K];
+    container C = {Hd x <= (1+eps) bc_k}; RPI = {Hd A^i x <= hc - bc_i, i < k*}."""
+    A = np.asarray(A, dtype=np.float64)
+    W, X, U = as_polytope(W), as_polytope(X), as_polytope(U)
+    K = np.atleast_2d(np.asarray(K, dtype=np.float64))
+    if A.shape[0] != A.shape[1]:
+        print("A needs to be a square matrix. Returning None")
+        return None
+    if np.any(W.b <= 0):
+        print("The polytope W does not contain the origin. Therefore, we return None")
+        return None
+    status = -1
+    Hw, hw = W.A, W.b
+    Hd = np.r_[X.A, -U.A @ K]
+    hd = np.r_[X.b, U.b]
+    nd = Hd.shape[0]
+    A_pwr = [np.eye(A.shape[0])]
+    for _ in range(s_max):
+        A_pwr.append(A_pwr[-1] @ A)
+    bc_all = np.zeros((nd, s_max))
+    k_star, found = 1, False
+    while k_star < s_max and not found:
+        HwAk = Hw @ A_pwr[k_star]
+        HdAj = Hd @ A_pwr[k_star - 1]
+        cond_a = all((1 + eps_var) * support(W, HwAk[i]) <= eps_var * hw[i] for i in range(Hw.shape[0]))
+        inc = np.array([support(W, HdAj[l]) for l in range(nd)])
+        bc_all[:, k_star - 1] = inc if k_star == 1 else bc_all[:, k_star - 2] + inc
+        cond_b = bool(np.all((1 + eps_var) * bc_all[:, k_star - 1] <= hd))
+        if cond_a and cond_b:
+            found, status = True, 0
+        else:
+            k_star += 1
+    if verbose:
+        print(f"k_star = {k_star}")
+    if not found:
+        print(f"In the RPI calculation, we reached the iteration maximum {s_max} without converging!")
+        return None, status
+    hc = (1 + eps_var) * bc_all[:, k_star - 1]
+    C = Polytope(Hd, hc)
+    HcAk = Hd @ A_pwr[k_star]
+    for i in range(nd):
+        if not (1 + eps_var) * support(C, HcAk[i]) <= eps_var * hc[i]:
+            print("The container set C does not fulfill the condition for calculating the RPI. Returning None")
+            return None, -1
+    H_rows = [Hd]
+    h_rows = [hc]
+    for i in range(1, k_star):
+        H_rows.append(Hd @ A_pwr[i])
+        h_rows.append(hc - bc_all[:, i - 1])
+    rpi = Polytope(np.vstack(H_rows), np.concatenate(h_rows))
+    rpi.k_star = k_star
+    if return_container:
+        return rpi, C, status
+    return rpi, status

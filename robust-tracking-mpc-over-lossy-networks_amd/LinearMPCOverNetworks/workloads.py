@@ -1,0 +1,45 @@
+"""Model definitions of the workloads named in BASELINE.json.
+
+The numbers are the reference's experiment constants: the linearised cartpole
+of `Results/results_linear_system.py:26-110` (masses, ZOH at 20 ms, Q/R, the
+disturbance box estimated by `estimate_W_for_Cartpole.py`, state/input boxes)
+and the double integrator of
+`Examples of Model Predictive Controllers/Example_of_Tube_Tracking_MPC.py:19-44`.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .control_lite import c2d
+from .polytope_lite import Polytope, box2poly
+
+
+def cartpole(Th: float = 0.02):
+    """Returns dict(A,B,Q,R,X,U,W) for the linearised cartpole (n=4, m=1)."""
+    M, m, b, I, g, l = 1.0, 0.1, 0.0, 0.001, 9.8, 0.5
+    p = I * (M + m) + M * m * l ** 2
+    Ac = np.array([[0, 1, 0, 0],
+                   [0, -(I + m * l ** 2) * b / p, -(m ** 2 * g * l ** 2) / p, 0],
+                   [0, 0, 0, 1],
+                   [0, -(m * l * b) / p, m * g * l * (M + m) / p, 0]], dtype=np.float64)
+    Bc = np.array([[0], [(I + m * l ** 2) / p], [0], [-m * l / p]], dtype=np.float64)
+    A, B = c2d(Ac, Bc, Th)
+    Q = np.diag([100.0, 10.0, 100.0, 10.0])
+    R = 0.1 * np.eye(1)
+    w = np.array([0.0001, 0.0027, 0.0003, 0.043])
+    W = box2poly(np.c_[-w, w])
+    xb = np.array([5.0, 5.0, 0.3, 2.0])
+    X = box2poly(np.c_[-xb, xb])
+    U = box2poly([[-10.0, 10.0]])
+    return dict(A=A, B=B, Q=Q, R=R, X=X, U=U, W=W, w_bound=w, name="cartpole")
+
+
+def double_integrator():
+    """Returns dict(A,B,Q,R,X,U,W) for the 2-state double integrator (n=2, m=1)."""
+    A = np.array([[1.0, 1.0], [0.0, 1.0]])
+    B = np.array([[0.0], [1.0]])
+    X = box2poly([[-8.0, 8.0]] * 2)
+    U = box2poly([[-1.0, 1.0]])
+    W = box2poly([[-0.1, 0.1]] * 2)
+    return dict(A=A, B=B, Q=np.eye(2), R=np.eye(1), X=X, U=U, W=W,
+                w_bound=np.array([0.1, 0.1]), name="double_integrator")
