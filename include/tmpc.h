@@ -93,6 +93,9 @@ const char *tmpc_last_error(const tmpc_handle *h);
  * Replaces generate_optimization_problem(fixed_initial_state)
  * (TubeTrackingMPC.py:104-156) [+ :253-299 when p->extended]: condenses the QP(s)
  * once, uploads them to HIP device `device`, allocates scratch.
+ * device < 0 builds a host-only handle: the condensed problem can be inspected
+ * (tmpc_get_dims / tmpc_get_condensed) but every solve call fails with TMPC_E_DEVICE --
+ * there is no CPU solve path in this library.
  */
 int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out);
 

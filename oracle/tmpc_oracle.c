@@ -172,6 +172,13 @@ static int build_sparse(const tmpc_problem *p, int variant, sparse_t *s) {
             s->P[(oxb + i) * nvar + oxb + j] += 2.0 * p->T[i * nx + j];
             s->Qr[(oxb + i) * nx + j] = -2.0 * p->T[i * nx + j];   /* -2 T ref on x_bar */
         }
+    if (aux) {
+        /* cost-free auxiliaries (:293): vanishing weight eps = 2e-6 min(diag R) so that the
+         * problem is strictly convex; same rule as the HIP library */
+        double rmin = p->R[0];
+        for (int i = 1; i < nu; ++i) if (p->R[i * nu + i] < rmin) rmin = p->R[i * nu + i];
+        for (int i = oxa; i < nvar; ++i) s->P[i * nvar + i] += 2e-6 * rmin;
+    }
     int er = 0, ir = 0;
     /* initial state */
     if (fixed) {
@@ -431,8 +438,6 @@ static double max_step(const double *s, const double *ds, const double *l, const
 static int polish(const form_t *f, work_t *w) {
     const int nv = f->nw, nc = f->nc;
     const double *Gs = f->Gs, *Hs = f->Hs, *Hinv = f->Hinv;
-    double hn = 1.0;
-    for (int i = 0; i < nc; ++i) { if (fabs(w->h[i]) > hn) hn = fabs(w->h[i]); }
     for (int i = 0; i < nc; ++i) { w->inW[i] = w->lam[i] > w->s[i]; w->yall[i] = w->lam[i]; }
     memcpy(w->zp, w->z, sizeof(double) * nv);
     for (int it = 0; it < 6; ++it) {
@@ -456,10 +461,10 @@ static int polish(const form_t *f, work_t *w) {
                     w->S[a * m + b] = v; w->S[b * m + a] = v;
                     if (a == b && v > dmax) dmax = v;
                 }
-            for (int a = 0; a < m; ++a) w->S[a * m + a] += 1e-8 * dmax;
+            for (int a = 0; a < m; ++a) w->S[a * m + a] += 1e-11 * dmax;
             if (chol(w->S, m)) return 0;
             for (int k = 0; k < m; ++k) w->y[k] = w->yall[w->W[k]];
-            for (int step = 0; step < 3; ++step) {
+            for (int step = 0; step < 4; ++step) {
                 for (int i = 0; i < nv; ++i) {           /* r1 = Hs z + q + G_W' y */
                     double v = w->q[i];
                     for (int j = 0; j < nv; ++j) v += Hs[i * nv + j] * w->zp[j];
@@ -482,16 +487,19 @@ static int polish(const form_t *f, work_t *w) {
             }
         }
         /* verify */
-        int nviol = 0, nneg = 0;
+        int nviol = 0, nneg = 0, nloose = 0;
         double ymax = 1.0;
         for (int k = 0; k < m; ++k) if (fabs(w->y[k]) > ymax) ymax = fabs(w->y[k]);
         for (int i = 0; i < nc; ++i) {
             const double *g = Gs + (size_t)i * nv; double v = -w->h[i];
             for (int j = 0; j < nv; ++j) v += g[j] * w->zp[j];
             w->r[i] = v;
-            if (!w->inW[i] && v > 1e-9 * hn) ++nviol;
+            const double hi = fabs(w->h[i]) > 1.0 ? fabs(w->h[i]) : 1.0;
+            if (!w->inW[i] && v > 1e-12 * hi) ++nviol;
+            if (w->inW[i] && fabs(v) > 1e-11 * hi) ++nloose;    /* working-set row not on its bound: not converged */
         }
-        for (int k = 0; k < m; ++k) if (w->y[k] < -1e-9 * ymax) ++nneg;
+        for (int k = 0; k < m; ++k) if (w->y[k] < -1e-10 * ymax) ++nneg;
+        if (nloose) return 0;
         if (nviol == 0 && nneg == 0) {
             memcpy(w->z, w->zp, sizeof(double) * nv);
             for (int i = 0; i < nc; ++i) { w->lam[i] = 0; w->s[i] = w->r[i] < 0 ? -w->r[i] : 0; }
@@ -499,8 +507,8 @@ static int polish(const form_t *f, work_t *w) {
             return 1;
         }
         for (int k = 0; k < m; ++k) w->yall[w->W[k]] = w->y[k];
-        for (int k = 0; k < m; ++k) if (w->y[k] < -1e-9 * ymax) { w->inW[w->W[k]] = 0; w->yall[w->W[k]] = 0; }
-        for (int i = 0; i < nc; ++i) if (!w->inW[i] && w->r[i] > 1e-9 * hn) {
+        for (int k = 0; k < m; ++k) if (w->y[k] < -1e-10 * ymax) { w->inW[w->W[k]] = 0; w->yall[w->W[k]] = 0; }
+        for (int i = 0; i < nc; ++i) if (!w->inW[i] && w->r[i] > 1e-12 * (fabs(w->h[i]) > 1.0 ? fabs(w->h[i]) : 1.0)) {
             int was = 0; for (int k = 0; k < m; ++k) if (w->W[k] == i) was = 1;
             if (!was) { w->inW[i] = 1; w->yall[i] = 0; }
         }

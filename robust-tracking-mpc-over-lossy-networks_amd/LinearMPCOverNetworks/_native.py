@@ -1,0 +1,192 @@
+"""ctypes binding of lib/libtmpc_hip.so (C ABI: include/tmpc.h).
+
+This is the only route from the Python classes to the solver: there is no CPU
+fall-back.  A missing library raises at import of the first solve/setup call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG, "lib", "libtmpc_hip.so")
+ABI_VERSION = 1
+
+_PTR_FIELDS = ["A", "B", "Q", "R", "P", "T", "K", "K_anc",
+               "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW"]
+_INT_FIELDS = ["nx", "nu", "N", "rx", "ru", "rT", "rZ", "rZW",
+               "fixed_x0", "extended", "literal_terminal_row", "max_iter"]
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_up = C.POINTER(C.c_uint8)
+
+
+class TmpcProblem(C.Structure):
+    """Field-for-field include/tmpc.h: tmpc_problem."""
+    _fields_ = ([(n, C.c_int32) for n in _INT_FIELDS] + [("tol", C.c_double)]
+                + [(n, _dp) for n in _PTR_FIELDS])
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_PKG, 'csrc')}` "
+                "(or __graft_entry__.build()).  There is no CPU solve path.")
+        L = C.CDLL(LIB_PATH)
+        L.tmpc_abi_version.restype = C.c_int
+        if L.tmpc_abi_version() != ABI_VERSION:
+            raise RuntimeError("libtmpc_hip.so ABI version mismatch")
+        L.tmpc_last_error.argtypes = [C.c_void_p]
+        L.tmpc_last_error.restype = C.c_char_p
+        L.tmpc_create.argtypes = [C.POINTER(TmpcProblem), C.c_int, C.POINTER(C.c_void_p)]
+        L.tmpc_create.restype = C.c_int
+        L.tmpc_destroy.argtypes = [C.c_void_p]
+        L.tmpc_destroy.restype = None
+        sig = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tmpc_solve_batch.argtypes = sig
+        L.tmpc_solve_batch.restype = C.c_int
+        L.tmpc_solve_batch_device.argtypes = sig
+        L.tmpc_solve_batch_device.restype = C.c_int
+        L.tmpc_synchronize.argtypes = [C.c_void_p]
+        L.tmpc_synchronize.restype = C.c_int
+        L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.tmpc_last_kernel_ms.restype = C.c_int
+        L.tmpc_get_dims.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
+        L.tmpc_get_dims.restype = C.c_int
+        L.tmpc_get_condensed.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        L.tmpc_get_condensed.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def pack_problem(d: dict):
+    """dict (TubeTrackingMPC._problem_dict) -> (TmpcProblem, keep-alive list)."""
+    p = TmpcProblem()
+    keep = []
+    nx, nu = int(d["nx"]), int(d["nu"])
+    p.nx, p.nu, p.N = nx, nu, int(d["N"])
+    p.fixed_x0 = int(d.get("fixed_x0", 0))
+    p.extended = int(d.get("extended", 0))
+    p.literal_terminal_row = int(d.get("literal_terminal_row", 1))
+    p.max_iter = int(d.get("max_iter", 0))
+    p.tol = float(d.get("tol", 0.0))
+    square = {"A": (nx, nx), "B": (nx, nu), "Q": (nx, nx), "R": (nu, nu), "P": (nx, nx), "T": (nx, nx),
+              "K": (nu, nx), "K_anc": (nu, nx)}
+    widths = {"Hx": nx, "Hu": nu, "HT": 2 * nx + nu, "HZ": nx, "HZW": nx}
+    rows = {}
+    for name in _PTR_FIELDS:
+        v = d.get(name)
+        if v is None:
+            setattr(p, name, _dp())
+            continue
+        a = np.ascontiguousarray(np.asarray(v, dtype=np.float64))
+        if name in square:
+            if a.size != square[name][0] * square[name][1]:
+                raise ValueError(f"{name} has {a.size} entries, expected shape {square[name]}")
+            a = np.ascontiguousarray(a.reshape(square[name]))
+        elif name in widths:
+            if a.ndim != 2 or a.shape[1] != widths[name]:
+                raise ValueError(f"{name} must have {widths[name]} columns, got shape {a.shape}")
+            rows[name] = a.shape[0]
+        else:                                   # right-hand sides
+            a = np.ascontiguousarray(a.reshape(-1))
+            rows[name] = a.shape[0]
+        keep.append(a)
+        setattr(p, name, a.ctypes.data_as(_dp))
+    for hk, Hk in (("hx", "Hx"), ("hu", "Hu"), ("hT", "HT"), ("hZ", "HZ"), ("hZW", "HZW")):
+        if rows.get(hk, 0) != rows.get(Hk, 0):
+            raise ValueError(f"{Hk} has {rows.get(Hk, 0)} rows but {hk} has {rows.get(hk, 0)} entries")
+    p.rx, p.ru, p.rT = rows.get("Hx", 0), rows.get("Hu", 0), rows.get("HT", 0)
+    p.rZ, p.rZW = rows.get("HZ", 0), rows.get("HZW", 0)
+    return p, keep
+
+
+class Handle:
+    def __init__(self, ptr, nx, nu, N, nvariants):
+        self.ptr, self.nx, self.nu, self.N, self.nvariants = ptr, nx, nu, N, nvariants
+
+    def error(self) -> str:
+        return lib().tmpc_last_error(self.ptr).decode()
+
+
+def create(problem: dict, device: int = 0) -> Handle:
+    L = lib()
+    p, _keep = pack_problem(problem)
+    h = C.c_void_p()
+    rc = L.tmpc_create(C.byref(p), int(device), C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"tmpc_create failed ({rc}): {L.tmpc_last_error(None).decode()}")
+    return Handle(h, p.nx, p.nu, p.N, 2 if p.extended else 1)
+
+
+def destroy(h: Handle):
+    if h is not None and h.ptr:
+        lib().tmpc_destroy(h.ptr)
+        h.ptr = None
+
+
+def get_dims(h: Handle, variant: int = 0):
+    nv, nc, npar = C.c_int32(), C.c_int32(), C.c_int32()
+    if lib().tmpc_get_dims(h.ptr, variant, C.byref(nv), C.byref(nc), C.byref(npar)) != 0:
+        raise RuntimeError("tmpc_get_dims failed")
+    return nv.value, nc.value, npar.value
+
+
+def get_condensed(h: Handle, variant: int = 0) -> dict:
+    nv, nc, _ = get_dims(h, variant)
+    out = dict(H=np.empty((nv, nv)), F1=np.empty((nv, h.nx)), F2=np.empty((nv, h.nx)),
+               G=np.empty((nc, nv)), g0=np.empty(nc), E=np.empty((nc, h.nx)))
+    rc = lib().tmpc_get_condensed(h.ptr, variant, *[out[k].ctypes.data_as(_dp) for k in ("H", "F1", "F2", "G", "g0", "E")])
+    if rc != 0:
+        raise RuntimeError("tmpc_get_condensed failed")
+    return out
+
+
+def solve_batch(h: Handle, x, r, variant=None, want_traj: bool = True) -> dict:
+    """Host-pointer entry (tmpc_solve_batch): numpy in, numpy out."""
+    B = x.shape[0]
+    nx, nu, N = h.nx, h.nu, h.N
+    out = dict(u_nom=np.empty((B, N, nu)), x_nom0=np.empty((B, nx)), xu_ss=np.empty((B, nx + nu)),
+               x_nom=np.empty((B, N + 1, nx)) if want_traj else None,
+               status=np.empty(B, np.int32), iters=np.empty(B, np.int32))
+    vptr = None
+    if variant is not None:
+        var = np.ascontiguousarray(np.broadcast_to(np.asarray(variant, dtype=np.uint8).reshape(-1), (B,)))
+        vptr = var.ctypes.data
+    rc = lib().tmpc_solve_batch(h.ptr, B, x.ctypes.data, r.ctypes.data, vptr,
+                                out["u_nom"].ctypes.data, out["x_nom0"].ctypes.data, out["xu_ss"].ctypes.data,
+                                out["x_nom"].ctypes.data if want_traj else None,
+                                out["status"].ctypes.data, out["iters"].ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"tmpc_solve_batch failed ({rc}): {h.error()}")
+    out["x_ss"] = out["xu_ss"][:, :nx]
+    out["u_ss"] = out["xu_ss"][:, nx:]
+    return out
+
+
+def solve_batch_device(h: Handle, B: int, x_ptr, r_ptr, var_ptr, u_ptr, x0_ptr, ss_ptr, xn_ptr, st_ptr, it_ptr):
+    """Device-pointer entry (tmpc_solve_batch_device): raw addresses (e.g. tensor.data_ptr())."""
+    rc = lib().tmpc_solve_batch_device(h.ptr, int(B), x_ptr, r_ptr, var_ptr, u_ptr, x0_ptr, ss_ptr, xn_ptr, st_ptr, it_ptr)
+    if rc != 0:
+        raise RuntimeError(f"tmpc_solve_batch_device failed ({rc}): {h.error()}")
+
+
+def synchronize(h: Handle):
+    if lib().tmpc_synchronize(h.ptr) != 0:
+        raise RuntimeError(h.error())
+
+
+def last_kernel_ms(h: Handle) -> float:
+    ms = C.c_float()
+    if lib().tmpc_last_kernel_ms(h.ptr, C.byref(ms)) != 0:
+        raise RuntimeError(h.error())
+    return float(ms.value)

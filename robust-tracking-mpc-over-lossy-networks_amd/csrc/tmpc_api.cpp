@@ -1,0 +1,295 @@
+// C ABI of libtmpc_hip.so (declared in include/tmpc.h).  Host side only: condenses the
+// problem (tmpc_condense.cpp), keeps it resident in HBM and enqueues the solve kernels
+// (tmpc_kernels.hip) on the handle's stream.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "tmpc_condense.hpp"
+#include "tmpc_device.hpp"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Variant {
+    tmpc::Condensed c;
+    tmpc::DeviceQP d{};
+    int nvp = 0, rpl = 0;
+    std::vector<void *> dev;     // device allocations of this variant
+};
+
+}  // namespace
+
+struct tmpc_handle {
+    int device = 0;
+    int n_cu = 0;
+    int nvariants = 0;
+    int nx = 0, nu = 0, N = 0;
+    Variant v[2];
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // staging buffers for the host-pointer entry point
+    int64_t cap = 0;
+    double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
+    uint8_t *d_var = nullptr;
+    int32_t *d_st = nullptr, *d_it = nullptr;
+    std::string err;
+};
+
+namespace {
+
+#define HIP_TRY(h, expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                  \
+            return TMPC_E_DEVICE;                                                          \
+        }                                                                                  \
+    } while (0)
+
+template <class T>
+int upload(tmpc_handle *h, Variant &v, const T *src, size_t n, const T **dst) {
+    void *p = nullptr;
+    HIP_TRY(h, hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+    v.dev.push_back(p);
+    if (n) HIP_TRY(h, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(p);
+    return TMPC_OK;
+}
+
+int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
+    const tmpc::Condensed &c = v.c;
+    if (!tmpc::pick_config(c.nv, c.nc, &v.nvp, &v.rpl)) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "condensed QP (nv=%d, nc=%d) is larger than the compiled kernels cover (nv<=16, nc<=512)", c.nv, c.nc);
+        h->err = buf;
+        return TMPC_E_UNSUPPORTED;
+    }
+    const int NVP = v.nvp, NCP = v.rpl * 64, nx = c.nx;
+    std::vector<double> Gt(static_cast<size_t>(NVP) * NCP, 0.0), Hs(static_cast<size_t>(NVP) * NVP, 0.0), Hinv(Hs.size(), 0.0);
+    for (int r = 0; r < c.nc; ++r)
+        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NCP + r] = c.Gs(r, j);
+    for (int i = 0; i < NVP; ++i)
+        for (int j = 0; j < NVP; ++j) {
+            const bool in = i < c.nv && j < c.nv;
+            Hs[static_cast<size_t>(i) * NVP + j] = in ? c.Hs(i, j) : (i == j ? 1.0 : 0.0);
+            Hinv[static_cast<size_t>(i) * NVP + j] = in ? c.Hinv(i, j) : (i == j ? 1.0 : 0.0);
+        }
+    tmpc::DeviceQP &d = v.d;
+    d.nx = c.nx; d.nu = c.nu; d.N = c.N; d.nv = c.nv; d.nc = c.nc; d.npar = c.npar; d.nth = c.nth;
+    d.off_theta = c.off_theta; d.off_x0 = c.off_x0; d.off_aux = c.off_aux;
+    d.max_iter = p.max_iter > 0 ? p.max_iter : 60;
+    d.tol = p.tol > 0 ? p.tol : 1e-7;
+    d.always_infeasible = c.always_infeasible ? 1 : 0;
+    int rc;
+    if ((rc = upload(h, v, Gt.data(), Gt.size(), &d.Gt))) return rc;
+    if ((rc = upload(h, v, Hs.data(), Hs.size(), &d.Hs))) return rc;
+    if ((rc = upload(h, v, Hinv.data(), Hinv.size(), &d.Hinv))) return rc;
+    if ((rc = upload(h, v, c.F1s.a.data(), c.F1s.a.size(), &d.F1s))) return rc;
+    if ((rc = upload(h, v, c.F2s.a.data(), c.F2s.a.size(), &d.F2s))) return rc;
+    if ((rc = upload(h, v, c.g0s.data(), c.g0s.size(), &d.g0s))) return rc;
+    if ((rc = upload(h, v, c.Es.a.data(), c.Es.a.size(), &d.Es))) return rc;
+    if ((rc = upload(h, v, c.gp0.data(), c.gp0.size(), &d.gp0))) return rc;
+    if ((rc = upload(h, v, c.Ep.a.data(), c.Ep.a.size(), &d.Ep))) return rc;
+    if ((rc = upload(h, v, c.Dv.data(), c.Dv.size(), &d.Dv))) return rc;
+    if ((rc = upload(h, v, c.Mth.a.data(), c.Mth.a.size(), &d.Mth))) return rc;
+    if ((rc = upload(h, v, p.A, static_cast<size_t>(nx) * nx, &d.A))) return rc;
+    if ((rc = upload(h, v, p.B, static_cast<size_t>(nx) * c.nu, &d.B))) return rc;
+    return TMPC_OK;
+}
+
+void free_staging(tmpc_handle *h) {
+    void *ptrs[] = {h->d_x, h->d_r, h->d_u, h->d_x0, h->d_ss, h->d_xn, h->d_var, h->d_st, h->d_it};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    h->d_x = h->d_r = h->d_u = h->d_x0 = h->d_ss = h->d_xn = nullptr;
+    h->d_var = nullptr; h->d_st = h->d_it = nullptr;
+    h->cap = 0;
+}
+
+int ensure_staging(tmpc_handle *h, int64_t B) {
+    if (B <= h->cap) return TMPC_OK;
+    free_staging(h);
+    const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B);
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_x), b * nx * sizeof(double)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_r), b * nx * sizeof(double)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_u), b * N * nu * sizeof(double)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_x0), b * nx * sizeof(double)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_ss), b * (nx + nu) * sizeof(double)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_xn), b * (N + 1) * nx * sizeof(double)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_var), b));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_st), b * sizeof(int32_t)));
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_it), b * sizeof(int32_t)));
+    h->cap = B;
+    return TMPC_OK;
+}
+
+int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
+            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters) {
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    for (int k = 0; k < h->nvariants; ++k) {
+        if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
+        Variant &v = h->v[k];
+        HIP_TRY(h, tmpc::launch_solve(v.d, v.nvp, v.rpl, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
+                                      iters, h->n_cu, h->stream));
+    }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    h->timed = true;
+    return TMPC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tmpc_abi_version(void) { return TMPC_ABI_VERSION; }
+
+const char *tmpc_last_error(const tmpc_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
+    if (!p || !out) { g_create_error = "tmpc_create: NULL argument"; return TMPC_E_INVALID; }
+    *out = nullptr;
+    if (p->nx <= 0 || p->nu <= 0 || p->N <= 0 || p->nx > 16) {
+        g_create_error = "tmpc_create: need 0 < nx <= 16, nu > 0, N > 0";
+        return TMPC_E_INVALID;
+    }
+    tmpc_handle *h = new (std::nothrow) tmpc_handle();
+    if (!h) { g_create_error = "out of memory"; return TMPC_E_NOMEM; }
+    h->device = device; h->nx = p->nx; h->nu = p->nu; h->N = p->N;
+    h->nvariants = p->extended ? 2 : 1;
+    int rc = TMPC_OK;
+    try {
+        for (int k = 0; k < h->nvariants && rc == TMPC_OK; ++k) {
+            const std::string msg = tmpc::condense(*p, k, h->v[k].c);
+            if (!msg.empty()) { h->err = "tmpc_create: " + msg; rc = TMPC_E_INVALID; }
+        }
+        if (rc == TMPC_OK && device >= 0) {
+            hipError_t e = hipSetDevice(device);
+            hipDeviceProp_t prop;
+            if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+            if (e != hipSuccess) {
+                h->err = std::string("tmpc_create: no usable HIP device: ") + hipGetErrorString(e);
+                rc = TMPC_E_DEVICE;
+            } else {
+                h->n_cu = prop.multiProcessorCount;
+                auto setup = [&]() -> int {
+                    HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+                    HIP_TRY(h, hipEventCreate(&h->ev0));
+                    HIP_TRY(h, hipEventCreate(&h->ev1));
+                    for (int k = 0; k < h->nvariants; ++k) {
+                        int r2 = upload_variant(h, h->v[k], *p);
+                        if (r2) return r2;
+                    }
+                    return TMPC_OK;
+                };
+                rc = setup();
+            }
+        }
+    } catch (const std::exception &ex) {
+        h->err = std::string("tmpc_create: ") + ex.what();
+        rc = TMPC_E_NOMEM;
+    }
+    if (rc != TMPC_OK) {
+        g_create_error = h->err;
+        tmpc_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return TMPC_OK;
+}
+
+void tmpc_destroy(tmpc_handle *h) {
+    if (!h) return;
+    if (h->device < 0) { delete h; return; }
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    free_staging(h);
+    for (int k = 0; k < 2; ++k)
+        for (void *p : h->v[k].dev) (void)hipFree(p);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int tmpc_solve_batch_device(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant,
+                            double *u_nom, double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters) {
+    if (!h) return TMPC_E_INVALID;
+    if (B < 0 || !x_k || !ref || !u_nom || !status || !iters) { h->err = "tmpc_solve_batch_device: NULL argument"; return TMPC_E_INVALID; }
+    if (B == 0) return TMPC_OK;
+    if (h->device < 0) { h->err = "host-only handle (device < 0): nothing can be solved without the GPU"; return TMPC_E_DEVICE; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    return enqueue(h, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
+}
+
+int tmpc_solve_batch(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant,
+                     double *u_nom, double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters) {
+    if (!h) return TMPC_E_INVALID;
+    if (B < 0 || !x_k || !ref || !u_nom || !status || !iters) { h->err = "tmpc_solve_batch: NULL argument"; return TMPC_E_INVALID; }
+    if (B == 0) return TMPC_OK;
+    if (variant)
+        for (int64_t i = 0; i < B; ++i)
+            if (variant[i] >= h->nvariants) { h->err = "tmpc_solve_batch: variant id out of range"; return TMPC_E_INVALID; }
+    if (h->device < 0) { h->err = "host-only handle (device < 0): nothing can be solved without the GPU"; return TMPC_E_DEVICE; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_staging(h, B);
+    if (rc) return rc;
+    const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B);
+    HIP_TRY(h, hipMemcpyAsync(h->d_x, x_k, b * nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(h->d_r, ref, b * nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (variant) HIP_TRY(h, hipMemcpyAsync(h->d_var, variant, b, hipMemcpyHostToDevice, h->stream));
+    rc = enqueue(h, B, h->d_x, h->d_r, variant ? h->d_var : nullptr, h->d_u, h->d_x0, h->d_ss, x_nom ? h->d_xn : nullptr,
+                 h->d_st, h->d_it);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpyAsync(u_nom, h->d_u, b * N * nu * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (x_nom0) HIP_TRY(h, hipMemcpyAsync(x_nom0, h->d_x0, b * nx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (xu_ss) HIP_TRY(h, hipMemcpyAsync(xu_ss, h->d_ss, b * (nx + nu) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (x_nom) HIP_TRY(h, hipMemcpyAsync(x_nom, h->d_xn, b * (N + 1) * nx * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(status, h->d_st, b * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipMemcpyAsync(iters, h->d_it, b * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_synchronize(tmpc_handle *h) {
+    if (!h) return TMPC_E_INVALID;
+    if (h->device < 0) return TMPC_OK;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_last_kernel_ms(tmpc_handle *h, float *ms) {
+    if (!h || !ms) return TMPC_E_INVALID;
+    if (!h->timed) { h->err = "tmpc_last_kernel_ms: no solve has been enqueued yet"; return TMPC_E_INVALID; }
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return TMPC_OK;
+}
+
+int tmpc_get_dims(const tmpc_handle *h, int variant, int32_t *nv, int32_t *nc, int32_t *npar) {
+    if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    const tmpc::Condensed &c = h->v[variant].c;
+    if (nv) *nv = c.nv;
+    if (nc) *nc = c.nc;
+    if (npar) *npar = c.npar;
+    return TMPC_OK;
+}
+
+int tmpc_get_condensed(const tmpc_handle *h, int variant, double *H, double *F1, double *F2, double *G, double *g0, double *E) {
+    if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    const tmpc::Condensed &c = h->v[variant].c;
+    if (H) std::memcpy(H, c.H.a.data(), c.H.a.size() * sizeof(double));
+    if (F1) std::memcpy(F1, c.F1.a.data(), c.F1.a.size() * sizeof(double));
+    if (F2) std::memcpy(F2, c.F2.a.data(), c.F2.a.size() * sizeof(double));
+    if (G) std::memcpy(G, c.G.a.data(), c.G.a.size() * sizeof(double));
+    if (g0) std::memcpy(g0, c.g0.data(), c.g0.size() * sizeof(double));
+    if (E) std::memcpy(E, c.E.a.data(), c.E.a.size() * sizeof(double));
+    return TMPC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,309 @@
+// See tmpc_condense.hpp.  Plain C++17, no dependencies.
+#include "tmpc_condense.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace tmpc {
+namespace {
+
+Mat from_ptr(const double *p, int r, int c) {
+    Mat m(r, c);
+    if (p) std::memcpy(m.a.data(), p, sizeof(double) * static_cast<size_t>(r) * c);
+    return m;
+}
+Mat mul(const Mat &A, const Mat &B) {
+    Mat C(A.r, B.c);
+    for (int i = 0; i < A.r; ++i)
+        for (int k = 0; k < A.c; ++k) {
+            const double a = A(i, k);
+            if (a == 0.0) continue;
+            for (int j = 0; j < B.c; ++j) C(i, j) += a * B(k, j);
+        }
+    return C;
+}
+Mat tr(const Mat &A) {
+    Mat T(A.c, A.r);
+    for (int i = 0; i < A.r; ++i)
+        for (int j = 0; j < A.c; ++j) T(j, i) = A(i, j);
+    return T;
+}
+Mat add(const Mat &A, const Mat &B, double sb = 1.0) {
+    Mat C = A;
+    for (size_t i = 0; i < C.a.size(); ++i) C.a[i] += sb * B.a[i];
+    return C;
+}
+void axpy(Mat &Y, const Mat &X, double s) {
+    for (size_t i = 0; i < Y.a.size(); ++i) Y.a[i] += s * X.a[i];
+}
+Mat eye(int n) {
+    Mat I(n, n);
+    for (int i = 0; i < n; ++i) I(i, i) = 1.0;
+    return I;
+}
+
+// A signal of the horizon as an affine function of (z, x_k, ref):  L z + Dx x_k + Dr ref
+struct Aff {
+    Mat L, Dx, Dr;
+    Aff() = default;
+    Aff(int dim, int nv, int nx) : L(dim, nv), Dx(dim, nx), Dr(dim, nx) {}
+};
+Aff sub(const Aff &a, const Aff &b) {
+    Aff c;
+    c.L = add(a.L, b.L, -1.0);
+    c.Dx = add(a.Dx, b.Dx, -1.0);
+    c.Dr = add(a.Dr, b.Dr, -1.0);
+    return c;
+}
+
+// Orthonormal basis of null(S), S: r x c with full row rank (Householder QR of S').
+bool null_space(const Mat &S, Mat &Nb) {
+    const int m = S.c, n = S.r;   // factor S' (m x n)
+    Mat M = tr(S), Q = eye(m);
+    std::vector<double> v(m);
+    for (int k = 0; k < n; ++k) {
+        double nrm = 0;
+        for (int i = k; i < m; ++i) nrm += M(i, k) * M(i, k);
+        nrm = std::sqrt(nrm);
+        if (nrm < 1e-12) return false;
+        const double alpha = M(k, k) > 0 ? -nrm : nrm;
+        std::fill(v.begin(), v.end(), 0.0);
+        for (int i = k; i < m; ++i) v[i] = M(i, k);
+        v[k] -= alpha;
+        double vn = 0;
+        for (int i = k; i < m; ++i) vn += v[i] * v[i];
+        if (vn < 1e-300) continue;
+        for (int j = k; j < n; ++j) {
+            double d = 0;
+            for (int i = k; i < m; ++i) d += v[i] * M(i, j);
+            d = 2 * d / vn;
+            for (int i = k; i < m; ++i) M(i, j) -= d * v[i];
+        }
+        for (int i = 0; i < m; ++i) {
+            double d = 0;
+            for (int j = k; j < m; ++j) d += Q(i, j) * v[j];
+            d = 2 * d / vn;
+            for (int j = k; j < m; ++j) Q(i, j) -= d * v[j];
+        }
+    }
+    Nb = Mat(m, m - n);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m - n; ++j) Nb(i, j) = Q(i, n + j);
+    return true;
+}
+
+// lower Cholesky in place; false if not positive definite
+bool cholesky(Mat &M) {
+    const int n = M.r;
+    for (int j = 0; j < n; ++j) {
+        double v = M(j, j);
+        for (int k = 0; k < j; ++k) v -= M(j, k) * M(j, k);
+        if (!(v > 0)) return false;
+        v = std::sqrt(v);
+        M(j, j) = v;
+        for (int i = j + 1; i < n; ++i) {
+            double t = M(i, j);
+            for (int k = 0; k < j; ++k) t -= M(i, k) * M(j, k);
+            M(i, j) = t / v;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
+    const int nx = p.nx, nu = p.nu, N = p.N;
+    const bool received = variant == 1;
+    if (received && !p.extended) return "variant 1 requested but problem is not extended";
+    const bool fixed = !received && p.fixed_x0;
+    const bool aux = received && p.literal_terminal_row;
+    const int rz = received ? p.rZW : (fixed ? 0 : p.rZ);
+    const double *HZp = received ? p.HZW : p.HZ, *hZp = received ? p.hZW : p.hZ;
+    if (!p.A || !p.B || !p.Q || !p.R || !p.P || !p.T) return "A, B, Q, R, P, T must be given";
+    if (p.rx < 0 || p.ru < 0 || p.rT < 0) return "negative row count";
+    if ((p.rx && (!p.Hx || !p.hx)) || (p.ru && (!p.Hu || !p.hu)) || (p.rT && (!p.HT || !p.hT)))
+        return "constraint block declared but pointer is NULL";
+    if (rz > 0 && (!HZp || !hZp)) return "initial-state set (HZ/HZW) missing";
+    if (!fixed && rz == 0) return "free initial state needs the set Z (rZ > 0)";
+
+    const Mat A = from_ptr(p.A, nx, nx), B = from_ptr(p.B, nx, nu), Q = from_ptr(p.Q, nx, nx),
+              R = from_ptr(p.R, nu, nu), P = from_ptr(p.P, nx, nx), T = from_ptr(p.T, nx, nx);
+    // steady-state parametrisation (TubeTrackingMPC.py:147)
+    Mat S(nx, nx + nu);
+    for (int i = 0; i < nx; ++i) {
+        for (int j = 0; j < nx; ++j) S(i, j) = A(i, j) - (i == j ? 1.0 : 0.0);
+        for (int j = 0; j < nu; ++j) S(i, nx + j) = B(i, j);
+    }
+    Mat Mth;
+    if (!null_space(S, Mth)) return "[A-I, B] does not have full row rank; steady states are not parametrised by nu values";
+    const int nth = Mth.c;
+
+    Condensed c;
+    c.nx = nx; c.nu = nu; c.N = N; c.nth = nth; c.Mth = Mth;
+    c.off_theta = N * nu;
+    int nv = N * nu + nth;
+    if (!fixed) { c.off_x0 = nv; nv += nx; }
+    if (aux) { c.off_aux = nv; nv += nx + nu; }
+    c.nv = nv;
+
+    auto selector = [&](int dim, int off) {
+        Aff s(dim, nv, nx);
+        for (int i = 0; i < dim; ++i) s.L(i, off + i) = 1.0;
+        return s;
+    };
+    std::vector<Aff> x(N + 1), u(N);
+    for (int i = 0; i < N; ++i) u[i] = selector(nu, i * nu);
+    if (fixed) { x[0] = Aff(nx, nv, nx); x[0].Dx = eye(nx); }
+    else x[0] = selector(nx, c.off_x0);
+    for (int i = 0; i < N; ++i) {
+        x[i + 1] = Aff(nx, nv, nx);
+        x[i + 1].L = add(mul(A, x[i].L), mul(B, u[i].L));
+        x[i + 1].Dx = mul(A, x[i].Dx);
+    }
+    Aff xbar(nx, nv, nx), ubar(nu, nv, nx);
+    for (int i = 0; i < nx; ++i) for (int j = 0; j < nth; ++j) xbar.L(i, c.off_theta + j) = Mth(i, j);
+    for (int i = 0; i < nu; ++i) for (int j = 0; j < nth; ++j) ubar.L(i, c.off_theta + j) = Mth(nx + i, j);
+    Aff rsig(nx, nv, nx);
+    rsig.Dr = eye(nx);
+
+    // ---- cost (TubeTrackingMPC.py:136,143,144):  sum ||e||^2_W  with e = L z + Dx x + Dr r
+    c.H = Mat(nv, nv); c.F1 = Mat(nv, nx); c.F2 = Mat(nv, nx);
+    auto add_cost = [&](const Aff &e, const Mat &W) {
+        const Mat LtW = mul(tr(e.L), W);
+        axpy(c.H, mul(LtW, e.L), 2.0);
+        axpy(c.F1, mul(LtW, e.Dx), 2.0);
+        axpy(c.F2, mul(LtW, e.Dr), 2.0);
+    };
+    for (int i = 0; i < N; ++i) {
+        add_cost(sub(x[i], xbar), Q);
+        add_cost(sub(u[i], ubar), R);
+    }
+    add_cost(sub(x[N], xbar), P);
+    add_cost(sub(xbar, rsig), T);
+    for (int i = 0; i < nv; ++i)
+        for (int j = 0; j < i; ++j) { const double a = 0.5 * (c.H(i, j) + c.H(j, i)); c.H(i, j) = c.H(j, i) = a; }
+    if (aux) {
+        // The auxiliaries of TubeTrackingMPC.py:293 carry no cost, so the QP is not strictly
+        // convex in them (any feasible value is optimal; the returned x, u, x_bar, u_bar do
+        // not depend on the choice).  A vanishing weight eps*|aux|^2, eps = 2e-6 min(diag R),
+        // selects one; it moves the reported minimiser by O(1e-11).
+        double rmin = R(0, 0);
+        for (int i = 1; i < nu; ++i) rmin = std::min(rmin, R(i, i));
+        for (int i = c.off_aux; i < nv; ++i) c.H(i, i) += 2e-6 * rmin;
+    }
+
+    // ---- constraints, in the reference's order
+    std::vector<std::vector<double>> Grow, Erow;
+    std::vector<double> hrow, hcn;
+    auto add_rows = [&](const Mat &Hc, const double *hc, const Aff &sig) {
+        const Mat G = mul(Hc, sig.L), E = mul(Hc, sig.Dx);
+        for (int r = 0; r < Hc.r; ++r) {
+            Grow.emplace_back(G.a.begin() + static_cast<size_t>(r) * nv, G.a.begin() + static_cast<size_t>(r + 1) * nv);
+            std::vector<double> e(nx);
+            for (int j = 0; j < nx; ++j) e[j] = -E(r, j);
+            Erow.push_back(e);
+            hrow.push_back(hc[r]);
+            double n2 = 0;
+            for (int j = 0; j < Hc.c; ++j) n2 += Hc(r, j) * Hc(r, j);
+            hcn.push_back(std::sqrt(n2));
+        }
+    };
+    if (!fixed) {
+        // Hz (x_k - x_0) <= hz  (TubeTrackingMPC.py:132 / :278)
+        Aff xk(nx, nv, nx);
+        xk.Dx = eye(nx);
+        add_rows(from_ptr(HZp, rz, nx), hZp, sub(xk, x[0]));
+    }
+    const Mat Hx = from_ptr(p.Hx, p.rx, nx), Hu = from_ptr(p.Hu, p.ru, nu);
+    for (int i = 0; i < N; ++i) {
+        add_rows(Hx, p.hx, x[i]);        // :139
+        add_rows(Hu, p.hu, u[i]);        // :140
+    }
+    {
+        // HT [x_T; x_bar; u_T] <= hT   (:149; for variant 1 literally :293)
+        const Aff xT = aux ? selector(nx, c.off_aux) : x[N];
+        const Aff uT = aux ? selector(nu, c.off_aux + nx) : ubar;
+        Aff st(2 * nx + nu, nv, nx);
+        for (int i = 0; i < nx; ++i) {
+            for (int j = 0; j < nv; ++j) { st.L(i, j) = xT.L(i, j); st.L(nx + i, j) = xbar.L(i, j); }
+            for (int j = 0; j < nx; ++j) st.Dx(i, j) = xT.Dx(i, j);
+        }
+        for (int i = 0; i < nu; ++i) for (int j = 0; j < nv; ++j) st.L(2 * nx + i, j) = uT.L(i, j);
+        add_rows(from_ptr(p.HT, p.rT, 2 * nx + nu), p.hT, st);
+    }
+
+    // ---- classify rows: iterate / x_k-only / constant
+    const int mi = static_cast<int>(Grow.size());
+    std::vector<int> keep, par;
+    for (int r = 0; r < mi; ++r) {
+        double gn = 0, en = 0;
+        for (double v : Grow[r]) gn += v * v;
+        for (double v : Erow[r]) en += v * v;
+        const double thr = 1e-11 * (1.0 + hcn[r]);
+        if (std::sqrt(gn) > thr) keep.push_back(r);
+        else if (std::sqrt(en) > thr) par.push_back(r);
+        else if (hrow[r] < -1e-9 * (1.0 + std::fabs(hrow[r]))) c.always_infeasible = true;
+    }
+    c.nc = static_cast<int>(keep.size());
+    c.npar = static_cast<int>(par.size());
+    c.G = Mat(c.nc, nv); c.E = Mat(c.nc, nx); c.g0.resize(c.nc);
+    c.Ep = Mat(c.npar, nx); c.gp0.resize(c.npar);
+    for (int a = 0; a < c.nc; ++a) {
+        for (int j = 0; j < nv; ++j) c.G(a, j) = Grow[keep[a]][j];
+        for (int j = 0; j < nx; ++j) c.E(a, j) = Erow[keep[a]][j];
+        c.g0[a] = hrow[keep[a]];
+    }
+    for (int a = 0; a < c.npar; ++a) {
+        for (int j = 0; j < nx; ++j) c.Ep(a, j) = Erow[par[a]][j];
+        c.gp0[a] = hrow[par[a]];
+    }
+
+    // ---- scaling: Jacobi on z, unit rows
+    c.Dv.resize(nv);
+    for (int i = 0; i < nv; ++i) {
+        if (!(c.H(i, i) > 0)) return "condensed Hessian has a non-positive diagonal entry";
+        c.Dv[i] = 1.0 / std::sqrt(c.H(i, i));
+    }
+    c.Hs = Mat(nv, nv); c.F1s = Mat(nv, nx); c.F2s = Mat(nv, nx);
+    for (int i = 0; i < nv; ++i) {
+        for (int j = 0; j < nv; ++j) c.Hs(i, j) = c.H(i, j) * c.Dv[i] * c.Dv[j];
+        for (int j = 0; j < nx; ++j) { c.F1s(i, j) = c.F1(i, j) * c.Dv[i]; c.F2s(i, j) = c.F2(i, j) * c.Dv[i]; }
+    }
+    c.Gs = Mat(c.nc, nv); c.Es = Mat(c.nc, nx); c.g0s.resize(c.nc);
+    for (int r = 0; r < c.nc; ++r) {
+        double n2 = 0;
+        for (int j = 0; j < nv; ++j) { const double v = c.G(r, j) * c.Dv[j]; c.Gs(r, j) = v; n2 += v * v; }
+        const double rn = std::sqrt(n2);
+        for (int j = 0; j < nv; ++j) c.Gs(r, j) /= rn;
+        for (int j = 0; j < nx; ++j) c.Es(r, j) = c.E(r, j) / rn;
+        c.g0s[r] = c.g0[r] / rn;
+    }
+    // Hs^-1 (used for the unconstrained minimiser and by the active-set refinement)
+    c.Hinv = Mat(nv, nv);
+    {
+        Mat L = c.Hs;
+        if (!cholesky(L)) return "condensed Hessian is not positive definite";
+        std::vector<double> col(nv);
+        for (int k = 0; k < nv; ++k) {
+            std::fill(col.begin(), col.end(), 0.0);
+            col[k] = 1.0;
+            for (int i = 0; i < nv; ++i) {
+                double t = col[i];
+                for (int j = 0; j < i; ++j) t -= L(i, j) * col[j];
+                col[i] = t / L(i, i);
+            }
+            for (int i = nv - 1; i >= 0; --i) {
+                double t = col[i];
+                for (int j = i + 1; j < nv; ++j) t -= L(j, i) * col[j];
+                col[i] = t / L(i, i);
+            }
+            for (int i = 0; i < nv; ++i) c.Hinv(i, k) = col[i];
+        }
+    }
+    out = std::move(c);
+    return "";
+}
+
+}  // namespace tmpc
