@@ -147,6 +147,13 @@ int tmpc_synchronize(tmpc_handle *h);
 int tmpc_last_kernel_ms(tmpc_handle *h, float *ms);
 
 /*
+ * Sum of the per-call device times (same HIP events as above) of all solve calls since the
+ * last reset, and their count (at most 4096 calls are tracked between resets).
+ * Synchronises the stream.  bench.py divides the two for the average launch duration.
+ */
+int tmpc_kernel_ms_total(tmpc_handle *h, float *total_ms, int32_t *launches, int reset);
+
+/*
  * Introspection for DESIGN.md / bench.py's roofline accounting: dimensions of the
  * condensed QP of `variant` as the kernels see it.
  *   nv   decision variables after condensing

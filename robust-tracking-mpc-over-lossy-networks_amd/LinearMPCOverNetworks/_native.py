@@ -33,6 +33,30 @@ class TmpcProblem(C.Structure):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so with the same SONAME as the system one.
+    Two HIP runtimes cannot both own the GPU in one process, and whichever is loaded first
+    wins the SONAME.  When torch is installed (bench.py and the multi-GPU driver use it for
+    device buffers and RCCL) bind this library to torch's copy, so that tensors, RCCL and the
+    solve kernels share one runtime regardless of import order."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -40,6 +64,7 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `make -C {os.path.join(_PKG, 'csrc')}` "
                 "(or __graft_entry__.build()).  There is no CPU solve path.")
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.tmpc_abi_version.restype = C.c_int
         if L.tmpc_abi_version() != ABI_VERSION:
@@ -60,6 +85,8 @@ def lib():
         L.tmpc_synchronize.restype = C.c_int
         L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.tmpc_last_kernel_ms.restype = C.c_int
+        L.tmpc_kernel_ms_total.argtypes = [C.c_void_p, C.POINTER(C.c_float), _ip, C.c_int]
+        L.tmpc_kernel_ms_total.restype = C.c_int
         L.tmpc_get_dims.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
         L.tmpc_get_dims.restype = C.c_int
         L.tmpc_get_condensed.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
@@ -190,3 +217,11 @@ def last_kernel_ms(h: Handle) -> float:
     if lib().tmpc_last_kernel_ms(h.ptr, C.byref(ms)) != 0:
         raise RuntimeError(h.error())
     return float(ms.value)
+
+
+def kernel_ms_total(h: Handle, reset: bool = True):
+    """(sum of per-call device ms, number of calls) since the last reset."""
+    ms, cnt = C.c_float(), C.c_int32()
+    if lib().tmpc_kernel_ms_total(h.ptr, C.byref(ms), C.byref(cnt), int(reset)) != 0:
+        raise RuntimeError(h.error())
+    return float(ms.value), int(cnt.value)

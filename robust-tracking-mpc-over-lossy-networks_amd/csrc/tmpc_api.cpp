@@ -34,6 +34,9 @@ struct tmpc_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
+    // event pairs of the launches since the last tmpc_kernel_ms_total(reset): per-launch device time
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+    size_t pool_used = 0;
     // staging buffers for the host-pointer entry point
     int64_t cap = 0;
     double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
@@ -131,6 +134,19 @@ int ensure_staging(tmpc_handle *h, int64_t B) {
 
 int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
             double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters) {
+    hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
+    if (h->pool_used < 4096) {
+        if (h->pool_used == h->pool.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIP_TRY(h, hipEventCreate(&a));
+            HIP_TRY(h, hipEventCreate(&b));
+            h->pool.emplace_back(a, b);
+        }
+        e0 = h->pool[h->pool_used].first;
+        e1 = h->pool[h->pool_used].second;
+        ++h->pool_used;
+    }
+    h->ev0 = e0; h->ev1 = e1;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
     for (int k = 0; k < h->nvariants; ++k) {
         if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
@@ -179,8 +195,12 @@ int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
                 h->n_cu = prop.multiProcessorCount;
                 auto setup = [&]() -> int {
                     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-                    HIP_TRY(h, hipEventCreate(&h->ev0));
-                    HIP_TRY(h, hipEventCreate(&h->ev1));
+                    for (int i = 0; i < 256; ++i) {       // timing events are created up front, not in the solve path
+                        hipEvent_t a = nullptr, b = nullptr;
+                        HIP_TRY(h, hipEventCreate(&a));
+                        HIP_TRY(h, hipEventCreate(&b));
+                        h->pool.emplace_back(a, b);
+                    }
                     for (int k = 0; k < h->nvariants; ++k) {
                         int r2 = upload_variant(h, h->v[k], *p);
                         if (r2) return r2;
@@ -211,8 +231,7 @@ void tmpc_destroy(tmpc_handle *h) {
     free_staging(h);
     for (int k = 0; k < 2; ++k)
         for (void *p : h->v[k].dev) (void)hipFree(p);
-    if (h->ev0) (void)hipEventDestroy(h->ev0);
-    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    for (auto &pr : h->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -268,6 +287,22 @@ int tmpc_last_kernel_ms(tmpc_handle *h, float *ms) {
     if (!h->timed) { h->err = "tmpc_last_kernel_ms: no solve has been enqueued yet"; return TMPC_E_INVALID; }
     HIP_TRY(h, hipEventSynchronize(h->ev1));
     HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return TMPC_OK;
+}
+
+int tmpc_kernel_ms_total(tmpc_handle *h, float *total_ms, int32_t *launches, int reset) {
+    if (!h) return TMPC_E_INVALID;
+    if (h->device < 0) { h->err = "host-only handle"; return TMPC_E_DEVICE; }
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    float sum = 0.f;
+    for (size_t i = 0; i < h->pool_used; ++i) {
+        float ms = 0.f;
+        HIP_TRY(h, hipEventElapsedTime(&ms, h->pool[i].first, h->pool[i].second));
+        sum += ms;
+    }
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = static_cast<int32_t>(h->pool_used);
+    if (reset) h->pool_used = 0;
     return TMPC_OK;
 }
 

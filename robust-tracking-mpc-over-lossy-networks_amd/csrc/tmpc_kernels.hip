@@ -692,12 +692,15 @@ hipError_t launch_one(const DeviceQP &qp, int variant_id, int64_t B, const doubl
                       int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
     constexpr int NCP = RPL * WAVE;
     const size_t lds = sizeof(double) * (static_cast<size_t>(NV) * NCP + 2 * NV * NV + WAVES_PER_BLOCK * WaveLds<NV>::TOTAL);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // > 64 KiB of dynamic LDS needs the opt-in once per device and instantiation
+    static bool attr_set[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, RPL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        attr_set = true;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     int64_t blocks = (B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     const int64_t cap = static_cast<int64_t>(n_cu) * 4;     // a few workgroups per CU, grid-stride over the batch

@@ -1,0 +1,204 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and
+the committed golden fixtures.  All tests here need the MI355X (-m gpu).
+
+Tolerance: BASELINE.json's north_star asks for u*_0 within 1e-6 of the reference CPU
+solver.  Both sides here run to the exact minimiser, so the assertions use 1e-8 on inputs
+(1e-6 would also pass) and 1e-9 on the steady state."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from oracle import qp_sparse
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+ATOL_U = 1e-8
+ATOL_SS = 1e-9
+S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
+
+
+@pytest.fixture(scope="module")
+def cartpole(hip_lib, oracle_lib):
+    mpc, w = common.make_mpc("cartpole", 10, True, create=True)
+    return mpc, w, Oracle(mpc._problem_dict())
+
+
+def test_native_library_is_the_one_in_tree(hip_lib):
+    assert os.path.samefile(hip_lib.LIB_PATH, os.path.join(common.PKG, "lib", "libtmpc_hip.so"))
+    assert hip_lib.lib().tmpc_abi_version() == 1
+
+
+def test_golden_fixture_cartpole_N10(cartpole, hip_lib):
+    """600 closed-loop (x_k, ref) pairs; expected outputs committed under tests/golden/."""
+    mpc, _, _ = cartpole
+    gold = np.load(os.path.join(common.GOLDEN, "cartpole_N10_oracle.npz"))
+    out = mpc._solve(S[:, :4], S[:, 4:])
+    assert np.array_equal(out["status"], gold["status"]) and np.all(out["status"] == 0)
+    np.testing.assert_allclose(out["u_nom"], gold["u_nom"], atol=ATOL_U, rtol=0)
+    np.testing.assert_allclose(out["u_nom"][:, 0], gold["u_nom"][:, 0], atol=ATOL_U, rtol=0)     # u*_0
+    np.testing.assert_allclose(out["x_nom0"], gold["x_nom0"], atol=1e-12, rtol=0)
+    np.testing.assert_allclose(out["xu_ss"], gold["xu_ss"], atol=ATOL_SS, rtol=0)
+    assert out["iters"].max() < 40
+
+
+def test_live_oracle_on_fresh_states(cartpole):
+    """Seeded disturbed closed loops (states the fixture does not contain)."""
+    mpc, w, orc = cartpole
+    rng = np.random.default_rng(20240301)
+    idx = rng.integers(0, len(S), 256)
+    X = S[idx, :4].copy()
+    R = S[idx, 4:].copy()
+    R[:, 0] += rng.uniform(-0.3, 0.3, len(idx))          # move the reference, keep x_k feasible
+    hip = mpc._solve(X, R)
+    ref = orc.solve(X, R)
+    assert np.array_equal(hip["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() > 200
+    np.testing.assert_allclose(hip["u_nom"][ok], ref["u_nom"][ok], atol=ATOL_U, rtol=0)
+    np.testing.assert_allclose(hip["xu_ss"][ok], ref["xu_ss"][ok], atol=ATOL_SS, rtol=0)
+    np.testing.assert_allclose(hip["x_nom"][ok], ref["x_nom"][ok], atol=1e-8, rtol=0)
+
+
+def test_kkt_certificate_of_hip_outputs(cartpole):
+    """Independent of the oracle's solver: the HIP outputs satisfy the KKT conditions of the QP
+    as the reference states it (TubeTrackingMPC.py:104-156)."""
+    mpc, _, _ = cartpole
+    p = mpc._problem_dict()
+    idx = np.arange(3, len(S), 37)
+    out = mpc._solve(S[idx, :4], S[idx, 4:])
+    for k, i in enumerate(idx):
+        qp = qp_sparse.build_sparse_qp(p, S[i, :4], S[i, 4:])
+        v = qp_sparse.pack(qp, out["x_nom"][k], out["u_nom"][k], out["x_ss"][k], out["u_ss"][k])
+        c = qp_sparse.kkt_certificate(qp, v)
+        assert c["r_eq"] < 1e-9 and c["r_ineq"] < 1e-9 and c["r_stat"] < 1e-7 and c["min_lam"] >= 0, c
+
+
+def test_edge_cases_infeasible_unconstrained_empty(cartpole, hip_lib):
+    mpc, _, orc = cartpole
+    X = np.array([[0.0, 0.0, 0.2, 0.0],        # angle outside the tightened set, x_0 fixed -> infeasible
+                  [0.5, 0.0, 0.0, 0.0],        # at the reference: unconstrained minimiser feasible
+                  [0.0, 0.0, 0.0, 0.0]])
+    R = np.array([[0.5, 0, 0, 0.0]] * 3)
+    out = mpc._solve(X, R)
+    ref = orc.solve(X, R)
+    assert list(out["status"]) == [2, 0, 0] == list(ref["status"])
+    assert np.all(np.isnan(out["u_nom"][0])) and np.all(np.isnan(out["xu_ss"][0])) and np.all(np.isnan(out["x_nom"][0]))
+    assert out["iters"][1] == 0
+    np.testing.assert_allclose(out["u_nom"][1], 0.0, atol=1e-9)
+    np.testing.assert_allclose(out["u_nom"][2], ref["u_nom"][2], atol=ATOL_U)
+    # a NaN-poisoned neighbour must not leak: instance 2 solved alone gives the same bits
+    alone = mpc._solve(X[2:3], R[2:3])
+    assert np.array_equal(alone["u_nom"][0], out["u_nom"][2])
+    # empty batch
+    e = mpc._solve(np.zeros((0, 4)), np.zeros((0, 4)))
+    assert e["u_nom"].shape == (0, 10, 1) and e["status"].shape == (0,)
+
+
+def test_reference_api_shapes_single_instance(cartpole):
+    """solve_optimization_problem / determine_packet with the reference's 1-D calling convention
+    (TubeTrackingMPC.py:170-227)."""
+    mpc, _, orc = cartpole
+    x, r = S[17, :4].copy(), S[17, 4:].copy()
+    x_nom, u_nom, x_ss, u_ss = mpc.solve_optimization_problem(x, r)
+    assert x_nom.shape == (4, 11) and u_nom.shape == (1, 10) and x_ss.shape == (4,) and u_ss.shape == (1,)
+    ref = orc.solve(x[None], r[None])
+    np.testing.assert_allclose(u_nom[0], ref["u_nom"][0, :, 0], atol=ATOL_U)
+    pkt = mpc.determine_packet(x.reshape(4, 1), r, 7)
+    assert pkt["q_t"] == 7 and pkt["U_t"].shape == (1, 11)
+    np.testing.assert_allclose(pkt["U_t"][0, -1], u_ss[0] + (mpc._K @ x_ss)[0], atol=1e-9)       # TubeTrackingMPC.py:217
+    assert len(mpc.get_computational_times()) == 1
+    mpc.reset_computational_times()
+    # infeasible -> four None / U_t None (TubeTrackingMPC.py:189-194, :220-221)
+    res = mpc.solve_optimization_problem(np.array([0.0, 0.0, 0.2, 0.0]), r)
+    assert res == (None, None, None, None)
+    assert mpc.determine_packet(np.array([0.0, 0.0, 0.2, 0.0]), r, 0)["U_t"] is None
+
+
+def test_full_batch_properties(cartpole):
+    """BASELINE config 2 size (B=4096): size-independent properties instead of a 4096-instance
+    oracle run: determinism, permutation equivariance, constraint satisfaction, dynamics."""
+    mpc, w, _ = cartpole
+    rng = np.random.default_rng(7)
+    idx = rng.integers(0, len(S), 4096)
+    X, R = S[idx, :4].copy(), S[idx, 4:].copy()
+    a = mpc._solve(X, R)
+    b = mpc._solve(X, R)
+    assert np.array_equal(a["u_nom"], b["u_nom"]) and np.array_equal(a["iters"], b["iters"])     # deterministic
+    perm = rng.permutation(4096)
+    c = mpc._solve(X[perm], R[perm])
+    assert np.array_equal(c["u_nom"], a["u_nom"][perm])                                          # equivariant
+    assert np.all(a["status"] == 0)
+    # duplicates of one instance inside the batch agree bit-for-bit with the fixture solve
+    first = {}
+    for k, i in enumerate(idx):
+        if i in first:
+            assert np.array_equal(a["u_nom"][k], a["u_nom"][first[i]])
+        else:
+            first[i] = k
+    # outputs obey the model and the tightened constraints of the reference formulation
+    A, Bm = w["A"], w["B"]
+    xn, un = a["x_nom"], a["u_nom"]
+    np.testing.assert_allclose(xn[:, 0], X, atol=1e-12)
+    np.testing.assert_allclose(xn[:, 1:], xn[:, :-1] @ A.T + un @ Bm.T, atol=1e-9)
+    assert np.max(np.abs(un)) <= mpc._Uc.b.max() + 1e-9
+    assert np.max(xn[:, :-1] @ mpc._Xc.A.T - mpc._Xc.b) < 1e-9
+    st = np.c_[xn[:, -1], a["xu_ss"]]
+    assert np.max(st @ mpc._Xf.A.T - mpc._Xf.b) < 1e-8
+    ss = a["xu_ss"]
+    np.testing.assert_allclose(ss[:, :4] @ (A - np.eye(4)).T + ss[:, 4:] @ Bm.T, 0, atol=1e-9)   # steady state (:147)
+
+
+def test_device_pointer_entry_with_torch(cartpole, hip_lib):
+    """tmpc_solve_batch_device on torch-allocated HBM buffers == host-pointer entry."""
+    import torch
+    mpc, _, _ = cartpole
+    h = mpc._handle
+    B = 512
+    X, R = S[:B, :4].copy(), S[:B, 4:].copy()
+    dev = torch.device("cuda:0")
+    x = torch.from_numpy(X).to(dev)
+    r = torch.from_numpy(R).to(dev)
+    u = torch.empty((B, 10, 1), dtype=torch.float64, device=dev)
+    x0 = torch.empty((B, 4), dtype=torch.float64, device=dev)
+    ss = torch.empty((B, 5), dtype=torch.float64, device=dev)
+    st = torch.empty(B, dtype=torch.int32, device=dev)
+    it = torch.empty(B, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    hip_lib.solve_batch_device(h, B, x.data_ptr(), r.data_ptr(), None, u.data_ptr(), x0.data_ptr(), ss.data_ptr(), None,
+                               st.data_ptr(), it.data_ptr())
+    hip_lib.synchronize(h)
+    assert hip_lib.last_kernel_ms(h) > 0
+    host = mpc._solve(X, R, want_traj=False)
+    assert np.array_equal(u.cpu().numpy(), host["u_nom"])
+    assert np.array_equal(st.cpu().numpy(), host["status"])
+
+
+@pytest.mark.parametrize("N", [5, 10])
+def test_config1_double_integrator_closed_loop(hip_lib, oracle_lib, N):
+    """BASELINE config 1: Example_of_Tube_Tracking_MPC.py (free initial state, Rakovic sets,
+    x0=[1,2], T=120, reference 5/-9/9/4, w ~ default_rng(1).uniform(-0.1,0.1)); N=5 as BASELINE
+    says and N=10 as the example does.  Every step's QP: HIP == oracle; applied input stays in U
+    (the example's own runtime check, :99-100)."""
+    mpc, w = common.make_mpc("double_integrator", N, False, create=True)
+    orc = Oracle(mpc._problem_dict())
+    A, B, K = w["A"], w["B"], mpc.get_ancillary_controller_gain()
+    rng = np.random.default_rng(1)
+    x = np.array([1.0, 2.0])
+    T = 120
+    ref = np.r_[5 * np.ones(30), -9 * np.ones(30), 9 * np.ones(30), 4 * np.ones(30)]
+    worst = 0.0
+    for t in range(T):
+        r = np.array([ref[t], 0.0])
+        x_nom, u_nom, x_ss, u_ss = mpc.solve_optimization_problem(x.copy(), r)
+        o = orc.solve(x[None], r[None])
+        assert o["status"][0] == 0
+        worst = max(worst, np.abs(u_nom[0] - o["u_nom"][0, :, 0]).max(), np.abs(x_nom[:, 0] - o["x_nom0"][0]).max())
+        u = u_nom[:, 0] - K @ (x - x_nom[:, 0])
+        assert w["U"].contains(u, 1e-7)
+        assert mpc._Z.contains(x - x_nom[:, 0], 1e-7)                  # x_k in x_0 (+) Z  (:132)
+        x = A @ x + B @ u + rng.uniform(-0.1, 0.1, 2)
+    assert worst < ATOL_U
+    assert abs(x[0] - 4.0) < 0.5
