@@ -112,15 +112,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    from LinearMPCOverNetworks import montecarlo
+
     def gather_stats():
         # the only exchange of the path: per-trajectory statistics, gathered once per sweep
         # (RCCL all-gather over xGMI; 8 B per trajectory, latency-bound)
         stats = torch.stack([st, it], dim=1).contiguous()
-        if world == 1:
-            return stats
-        gathered = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(gathered, stats)
-        return torch.cat(gathered, dim=0)
+        return montecarlo.gather_statistics(stats, world * B, rank, world)
 
     for _ in range(args.warmup):
         step()

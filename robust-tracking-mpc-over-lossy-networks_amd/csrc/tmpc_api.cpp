@@ -104,6 +104,16 @@ int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload(h, v, c.Mth.a.data(), c.Mth.a.size(), &d.Mth))) return rc;
     if ((rc = upload(h, v, p.A, static_cast<size_t>(nx) * nx, &d.A))) return rc;
     if ((rc = upload(h, v, p.B, static_cast<size_t>(nx) * c.nu, &d.B))) return rc;
+    d.dbg = nullptr;
+#ifdef TMPC_STAMPS
+    {
+        void *dbgp = nullptr;
+        HIP_TRY(h, hipMalloc(&dbgp, 16 * sizeof(long long)));
+        HIP_TRY(h, hipMemset(dbgp, 0, 16 * sizeof(long long)));
+        v.dev.push_back(dbgp);
+        d.dbg = static_cast<long long *>(dbgp);
+    }
+#endif
     return TMPC_OK;
 }
 
@@ -305,6 +315,15 @@ int tmpc_kernel_ms_total(tmpc_handle *h, float *total_ms, int32_t *launches, int
     if (reset) h->pool_used = 0;
     return TMPC_OK;
 }
+
+#ifdef TMPC_STAMPS
+int tmpc_debug_stamps(tmpc_handle *h, int variant, long long *out12) {
+    if (!h || !out12) return TMPC_E_INVALID;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out12, h->v[variant].d.dbg, 12 * sizeof(long long), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+#endif
 
 int tmpc_get_dims(const tmpc_handle *h, int variant, int32_t *nv, int32_t *nc, int32_t *npar) {
     if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;

@@ -31,6 +31,7 @@ struct DeviceQP {
     const double *Mth;    // [nx+nu][nth]
     const double *A;      // [nx][nx]
     const double *B;      // [nx][nu]
+    long long *dbg;       // diagnostic builds only (TMPC_STAMPS); nullptr otherwise
 };
 
 // Chooses the smallest compiled (NVP, RPL) that covers (nv, nc); false if none does.
