@@ -19,7 +19,7 @@ thread_local std::string g_create_error;
 struct Variant {
     tmpc::Condensed c;
     tmpc::DeviceQP d{};
-    int nvp = 0, rpl = 0;
+    tmpc::KernelShape shape;
     std::vector<void *> dev;     // device allocations of this variant
 };
 
@@ -68,16 +68,33 @@ int upload(tmpc_handle *h, Variant &v, const T *src, size_t n, const T **dst) {
 
 int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const tmpc::Condensed &c = v.c;
-    if (!tmpc::pick_config(c.nv, c.nc, &v.nvp, &v.rpl)) {
-        char buf[160];
-        std::snprintf(buf, sizeof buf, "condensed QP (nv=%d, nc=%d) is larger than the compiled kernels cover (nv<=16, nc<=512)", c.nv, c.nc);
-        h->err = buf;
-        return TMPC_E_UNSUPPORTED;
+    int nd = c.nd, ncc = c.ncc, kc = c.kc;
+    if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) {
+        nd = c.nc; ncc = 0; kc = 0;                       // no factored shape compiled: all rows dense
+        if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) {
+            char buf[200];
+            std::snprintf(buf, sizeof buf, "condensed QP (nv=%d, rows=%d of which %d factored with width %d) is outside the compiled kernel shapes",
+                          c.nv, c.nc, c.ncc, c.kc);
+            h->err = buf;
+            return TMPC_E_UNSUPPORTED;
+        }
     }
-    const int NVP = v.nvp, NCP = v.rpl * 64, nx = c.nx;
-    std::vector<double> Gt(static_cast<size_t>(NVP) * NCP, 0.0), Hs(static_cast<size_t>(NVP) * NVP, 0.0), Hinv(Hs.size(), 0.0);
-    for (int r = 0; r < c.nc; ++r)
-        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NCP + r] = c.Gs(r, j);
+    const int NVP = v.shape.nvp, NDP = v.shape.rd * 64, KCP = v.shape.kcp, NCCP = v.shape.rc * 64, nx = c.nx;
+    const int slots = (v.shape.rd + v.shape.rc) * 64;
+    std::vector<double> Gt(static_cast<size_t>(NVP) * NDP, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
+        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), Hs(static_cast<size_t>(NVP) * NVP, 0.0), Hinv(Hs.size(), 0.0),
+        g0p(slots, 1.0), Esp(static_cast<size_t>(slots) * nx, 0.0);
+    for (int r = 0; r < nd; ++r)
+        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NDP + r] = c.Gs(r, j);
+    for (int r = 0; r < ncc; ++r)
+        for (int a = 0; a < kc; ++a) Hct[static_cast<size_t>(a) * NCCP + r] = c.Hc(r, a);
+    for (int a = 0; a < kc; ++a)
+        for (int j = 0; j < c.nv; ++j) Psi[static_cast<size_t>(a) * NVP + j] = c.Psi(a, j);
+    for (int r = 0; r < c.nc; ++r) {
+        const int slot = r < nd ? r : NDP + (r - nd);
+        g0p[slot] = c.g0s[r];
+        for (int j = 0; j < nx; ++j) Esp[static_cast<size_t>(slot) * nx + j] = c.Es(r, j);
+    }
     for (int i = 0; i < NVP; ++i)
         for (int j = 0; j < NVP; ++j) {
             const bool in = i < c.nv && j < c.nv;
@@ -86,18 +103,21 @@ int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         }
     tmpc::DeviceQP &d = v.d;
     d.nx = c.nx; d.nu = c.nu; d.N = c.N; d.nv = c.nv; d.nc = c.nc; d.npar = c.npar; d.nth = c.nth;
+    d.nd = nd; d.ncc = ncc; d.kc = kc;
     d.off_theta = c.off_theta; d.off_x0 = c.off_x0; d.off_aux = c.off_aux;
     d.max_iter = p.max_iter > 0 ? p.max_iter : 60;
     d.tol = p.tol > 0 ? p.tol : 1e-7;
     d.always_infeasible = c.always_infeasible ? 1 : 0;
     int rc;
     if ((rc = upload(h, v, Gt.data(), Gt.size(), &d.Gt))) return rc;
+    if ((rc = upload(h, v, Hct.data(), Hct.size(), &d.Hct))) return rc;
+    if ((rc = upload(h, v, Psi.data(), Psi.size(), &d.Psi))) return rc;
     if ((rc = upload(h, v, Hs.data(), Hs.size(), &d.Hs))) return rc;
     if ((rc = upload(h, v, Hinv.data(), Hinv.size(), &d.Hinv))) return rc;
     if ((rc = upload(h, v, c.F1s.a.data(), c.F1s.a.size(), &d.F1s))) return rc;
     if ((rc = upload(h, v, c.F2s.a.data(), c.F2s.a.size(), &d.F2s))) return rc;
-    if ((rc = upload(h, v, c.g0s.data(), c.g0s.size(), &d.g0s))) return rc;
-    if ((rc = upload(h, v, c.Es.a.data(), c.Es.a.size(), &d.Es))) return rc;
+    if ((rc = upload(h, v, g0p.data(), g0p.size(), &d.g0p))) return rc;
+    if ((rc = upload(h, v, Esp.data(), Esp.size(), &d.Esp))) return rc;
     if ((rc = upload(h, v, c.gp0.data(), c.gp0.size(), &d.gp0))) return rc;
     if ((rc = upload(h, v, c.Ep.a.data(), c.Ep.a.size(), &d.Ep))) return rc;
     if ((rc = upload(h, v, c.Dv.data(), c.Dv.size(), &d.Dv))) return rc;
@@ -161,7 +181,7 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     for (int k = 0; k < h->nvariants; ++k) {
         if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
         Variant &v = h->v[k];
-        HIP_TRY(h, tmpc::launch_solve(v.d, v.nvp, v.rpl, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
+        HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
                                       iters, h->n_cu, h->stream));
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));

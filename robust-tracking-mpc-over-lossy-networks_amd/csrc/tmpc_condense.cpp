@@ -197,6 +197,8 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     // ---- constraints, in the reference's order
     std::vector<std::vector<double>> Grow, Erow;
     std::vector<double> hrow, hcn;
+    std::vector<int> rowblk, rowidx;      // block id (1 = terminal) and row number inside its block
+    int cur_blk = 0;
     auto add_rows = [&](const Mat &Hc, const double *hc, const Aff &sig) {
         const Mat G = mul(Hc, sig.L), E = mul(Hc, sig.Dx);
         for (int r = 0; r < Hc.r; ++r) {
@@ -208,6 +210,8 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
             double n2 = 0;
             for (int j = 0; j < Hc.c; ++j) n2 += Hc(r, j) * Hc(r, j);
             hcn.push_back(std::sqrt(n2));
+            rowblk.push_back(cur_blk);
+            rowidx.push_back(r);
         }
     };
     if (!fixed) {
@@ -231,7 +235,30 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
             for (int j = 0; j < nx; ++j) st.Dx(i, j) = xT.Dx(i, j);
         }
         for (int i = 0; i < nu; ++i) for (int j = 0; j < nv; ++j) st.L(2 * nx + i, j) = uT.L(i, j);
+        cur_blk = 1;
         add_rows(from_ptr(p.HT, p.rT, 2 * nx + nu), p.hT, st);
+        cur_blk = 0;
+    }
+    // factored form of the terminal block: rows = HcT * PsiT with
+    //   PsiT = [x_T map (nx rows); theta selector (nth rows); u_aux selector (nu rows, variant 1 only)]
+    const int kT = nx + nth + (aux ? nu : 0);
+    Mat PsiT(kT, nv), HcT(p.rT, kT);
+    {
+        const Aff xT = aux ? selector(nx, c.off_aux) : x[N];
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nv; ++j) PsiT(i, j) = xT.L(i, j);
+        for (int i = 0; i < nth; ++i) PsiT(nx + i, c.off_theta + i) = 1.0;
+        if (aux) for (int i = 0; i < nu; ++i) PsiT(nx + nth + i, c.off_aux + nx + i) = 1.0;
+        const Mat HT = from_ptr(p.HT, p.rT, 2 * nx + nu);
+        for (int r = 0; r < p.rT; ++r) {
+            for (int j = 0; j < nx; ++j) HcT(r, j) = HT(r, j);
+            for (int j = 0; j < nth; ++j) {
+                double v = 0;
+                for (int i = 0; i < nx; ++i) v += HT(r, nx + i) * Mth(i, j);
+                if (!aux) for (int i = 0; i < nu; ++i) v += HT(r, 2 * nx + i) * Mth(nx + i, j);
+                HcT(r, nx + j) = v;
+            }
+            if (aux) for (int j = 0; j < nu; ++j) HcT(r, nx + nth + j) = HT(r, 2 * nx + j);
+        }
     }
 
     // ---- classify rows: iterate / x_k-only / constant
@@ -245,6 +272,20 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         if (std::sqrt(gn) > thr) keep.push_back(r);
         else if (std::sqrt(en) > thr) par.push_back(r);
         else if (hrow[r] < -1e-9 * (1.0 + std::fabs(hrow[r]))) c.always_infeasible = true;
+    }
+    // the terminal block is kept in factored form when that pays (many rows, small rank); its rows
+    // then go last.  Everything else, in the reference's order, is "dense".
+    {
+        int nterm = 0;
+        for (int r : keep) nterm += rowblk[r] == 1;
+        const bool compact = nterm >= 64 && kT + 3 <= nv;
+        std::vector<int> dense_rows, term_rows;
+        for (int r : keep) ((compact && rowblk[r] == 1) ? term_rows : dense_rows).push_back(r);
+        keep = dense_rows;
+        keep.insert(keep.end(), term_rows.begin(), term_rows.end());
+        c.nd = static_cast<int>(dense_rows.size());
+        c.ncc = static_cast<int>(term_rows.size());
+        c.kc = compact ? kT : 0;
     }
     c.nc = static_cast<int>(keep.size());
     c.npar = static_cast<int>(par.size());
@@ -279,6 +320,25 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         for (int j = 0; j < nv; ++j) c.Gs(r, j) /= rn;
         for (int j = 0; j < nx; ++j) c.Es(r, j) = c.E(r, j) / rn;
         c.g0s[r] = c.g0[r] / rn;
+    }
+    if (c.ncc > 0) {
+        c.Psi = Mat(c.kc, nv);
+        c.Hc = Mat(c.ncc, c.kc);
+        for (int a = 0; a < c.kc; ++a) for (int j = 0; j < nv; ++j) c.Psi(a, j) = PsiT(a, j) * c.Dv[j];
+        double worst = 0;
+        for (int r = 0; r < c.ncc; ++r) {
+            const int src = rowidx[keep[c.nd + r]];
+            double n2 = 0;
+            for (int j = 0; j < nv; ++j) { const double v = c.G(c.nd + r, j) * c.Dv[j]; n2 += v * v; }
+            const double rn = std::sqrt(n2);
+            for (int a = 0; a < c.kc; ++a) c.Hc(r, a) = HcT(src, a) / rn;
+            for (int j = 0; j < nv; ++j) {           // consistency of the factorisation with the dense rows
+                double v = 0;
+                for (int a = 0; a < c.kc; ++a) v += c.Hc(r, a) * c.Psi(a, j);
+                worst = std::max(worst, std::fabs(v - c.Gs(c.nd + r, j)));
+            }
+        }
+        if (worst > 1e-10) return "internal error: factored terminal block does not reproduce its rows";
     }
     // Hs^-1 (used for the unconstrained minimiser and by the active-set refinement)
     c.Hinv = Mat(nv, nv);

@@ -46,6 +46,13 @@ struct Condensed {
     std::vector<double> Dv;
     Mat Hs, Hinv, Gs, Es, F1s, F2s;
     std::vector<double> g0s;
+    // Row order: the first `nd` rows are "dense" (general rows of Gs); the last `ncc` rows are the
+    // terminal block in factored form  Gs[nd + r, :] = Hc(r, :) * Psi :  the terminal inequality
+    // (TubeTrackingMPC.py:149) acts on [x_N; x_bar; u_bar] only, i.e. on kc = nx + nth (+ nu)
+    // combinations of z, so its rows have rank kc << nv.  ncc == 0 when the block is kept dense.
+    int nd = 0, ncc = 0, kc = 0;
+    Mat Psi;     // kc x nv, scaled with Dv
+    Mat Hc;      // ncc x kc, rows scaled like Gs
 };
 
 // Builds variant 0 (base problem) or 1 (packet-received problem).  Returns "" on

@@ -10,21 +10,25 @@
 
 namespace tmpc {
 
-// All pointers are device pointers owned by the handle.  NVP = padded variable count,
-// NCP = padded row count of the kernel instantiation chosen for this variant.
+// All pointers are device pointers owned by the handle.  The kernel instantiation chosen for a
+// variant is (NVP, RD, KCP, RC): padded variable count, 64-row slots of dense rows, padded width
+// and 64-row slots of the factored terminal block (KCP = RC = 0: everything dense).
 struct DeviceQP {
     int nx, nu, N;
     int nv, nc, npar, nth;
+    int nd, ncc, kc;      // dense rows, factored rows (nc = nd + ncc), factor width
     int off_theta, off_x0, off_aux;
     int max_iter, always_infeasible;
     double tol;
-    const double *Gt;     // [NVP][NCP]  scaled G, transposed, zero padded
-    const double *Hs;     // [NVP][NVP]  scaled Hessian, identity on the padding
+    const double *Gt;     // [NVP][RD*64]   scaled dense rows, transposed, zero padded
+    const double *Hct;    // [KCP][RC*64]   factored rows' left factor, transposed, zero padded
+    const double *Psi;    // [KCP][NVP]     factored rows' right factor
+    const double *Hs;     // [NVP][NVP]     scaled Hessian, identity on the padding
     const double *Hinv;   // [NVP][NVP]
     const double *F1s;    // [nv][nx]
     const double *F2s;    // [nv][nx]
-    const double *g0s;    // [nc]
-    const double *Es;     // [nc][nx]
+    const double *g0p;    // [(RD+RC)*64]      right-hand side offsets, slot layout (padding rows: 1)
+    const double *Esp;    // [(RD+RC)*64][nx]  right-hand side dependence on x_k, slot layout
     const double *gp0;    // [npar]
     const double *Ep;     // [npar][nx]
     const double *Dv;     // [nv]
@@ -34,11 +38,16 @@ struct DeviceQP {
     long long *dbg;       // diagnostic builds only (TMPC_STAMPS); nullptr otherwise
 };
 
-// Chooses the smallest compiled (NVP, RPL) that covers (nv, nc); false if none does.
-bool pick_config(int nv, int nc, int *nvp, int *rpl);
-size_t lds_bytes(int nvp, int rpl);
+struct KernelShape {
+    int nvp = 0, rd = 0, kcp = 0, rc = 0;
+};
 
-hipError_t launch_solve(const DeviceQP &qp, int nvp, int rpl, int variant_id, int64_t B, const double *x_k,
+// Chooses the smallest compiled shape that covers the variant; false if none does.  When no
+// factored shape fits, the caller may retry with everything dense (kc = 0, nd = nc).
+bool pick_config(int nv, int nd, int kc, int ncc, KernelShape *shape);
+size_t lds_bytes(const KernelShape &shape);
+
+hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, int variant_id, int64_t B, const double *x_k,
                         const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss,
                         double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream);
 

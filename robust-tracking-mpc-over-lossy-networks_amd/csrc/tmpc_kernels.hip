@@ -12,7 +12,10 @@
 //         min 1/2 z'Hs z + q'z  s.t.  Gs z + s = h, s >= 0
 //      rows of Gs are spread over the lanes (row r lives on lane r % 64, slot r / 64), the
 //      per-row state (s, lambda, r_p, 1/s, ...) stays in registers, Gs is staged once per
-//      workgroup in LDS (column-major, so a lane-per-row read is conflict free).  The
+//      workgroup in LDS (column-major, so a lane-per-row read is conflict free); the rows of
+//      the terminal block are kept factored, Gs_T = Hc * Psi with Hc only nx+nth wide
+//      (tmpc_condense.hpp), which cuts their share of every sweep by nv/kc and of G'DG by
+//      (nv/kc)^2.  The
 //      normal matrix M = Hs + Gs' D Gs is accumulated per lane in registers, a few
 //      columns of its lower triangle at a time (the full triangle does not fit the 256
 //      directly addressable VGPRs next to the row state), and summed across the wave
@@ -30,6 +33,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <utility>
 
 #include "tmpc_device.hpp"
 
@@ -39,7 +43,7 @@ namespace {
 
 constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
-constexpr int WCAP = 32;          // max rows in the refinement's working set
+constexpr int WCAP = 24;          // max rows in the refinement's working set
 constexpr int RED_ROWS = 16;      // entries per transposition round
 constexpr int RED_STRIDE = 65;    // 64 lanes + 1 pad: conflict-free transposed reads
 
@@ -142,6 +146,7 @@ template <int NV> struct Blocks;
 template <> struct Blocks<8>  { static constexpr int n = 2; static constexpr int b[3] = {0, 3, 8}; };
 template <> struct Blocks<12> { static constexpr int n = 3; static constexpr int b[4] = {0, 3, 7, 12}; };
 template <> struct Blocks<16> { static constexpr int n = 5; static constexpr int b[6] = {0, 2, 4, 7, 11, 16}; };
+template <> struct Blocks<24> { static constexpr int n = 9; static constexpr int b[10] = {0, 2, 4, 6, 8, 10, 13, 16, 19, 24}; };
 
 // ---- nv x nv solve, rows distributed over lanes.
 // Lane i (< NV) holds row i of the symmetric positive definite M in registers.  Gaussian
@@ -186,45 +191,92 @@ __device__ __forceinline__ void rows_backsub(const double (&row)[NV], double b, 
     }
 }
 
-// per-wave LDS workspace (doubles), see solve_kernel
-template <int NV, int RPL>
-struct WaveLds {
-    static constexpr int NT = NV * (NV + 1) / 2;
-    static constexpr int RED = RED_ROWS * RED_STRIDE;                       // transposition tile
-    static constexpr int POL = NV * WCAP + WCAP * (WCAP + 1) + 4 * WCAP;   // T, S, y, dy, W(idx)
-    static constexpr int BIG = RED > POL ? RED : POL;                       // the two are never live together
-    static constexpr int SUMS = NT + 2 * NV + 8;                            // reduced totals of a sweep
-    static constexpr int HROW = RPL * WAVE;                                 // right-hand side h, [slot][lane]
-    static constexpr int VEC = 8 * NV + 32;                                 // q, z, cost gradient, x_k, ref, scratch
-    static constexpr int TOTAL = BIG + SUMS + HROW + VEC;
+// compile-time description of one kernel instantiation
+template <int NV_, int RD_, int KC_, int RC_>
+struct Shape {
+    static constexpr int NV = NV_, RD = RD_, KC = KC_, RC = RC_;
+    static constexpr int KCA = KC_ > 0 ? KC_ : 1;            // array extents must be positive
+    static constexpr int RT = RD_ + RC_;                     // 64-row slots per lane
+    static constexpr int NDP = RD_ * WAVE, NCCP = RC_ * WAVE;
+    static constexpr int NT = NV_ * (NV_ + 1) / 2, KT = KC_ * (KC_ + 1) / 2;
 };
 
-// One sweep over the rows of this lane for columns [J0, J1) of the lower triangle of G'DG.
-// FIRST also forms r_p and 1/s; LAST also accumulates G'(d.r_p), G'lam and the gap.
-template <int NV, int RPL, int J0, int J1, bool FIRST, bool LAST>
-__device__ __forceinline__ void sweep_a(const double *Gt, const double *hw, const double (&z)[NV],
-                                        const double (&s)[RPL], const double (&lam)[RPL], double (&rp)[RPL], double (&rs)[RPL],
-                                        double *red, double *sums, int lane, int nc) {
-    constexpr int NCP = RPL * WAVE;
+// per-wave LDS workspace (doubles), see solve_kernel
+template <class SH>
+struct WaveLds {
+    static constexpr int RED = RED_ROWS * RED_STRIDE;                                   // transposition tile
+    static constexpr int POL = 2 * SH::NV * WCAP + WCAP * (WCAP + 1) + 4 * WCAP;       // G_W, T, S, y, dy, W(idx)
+    static constexpr int BIG = RED > POL ? RED : POL;                                   // never live together
+    static constexpr int SUMS = SH::NT + 2 * SH::NV + 8;                                // dense totals of a sweep
+    static constexpr int CSUMS = SH::KT + 2 * SH::KC + 8;                               // factored-block totals
+    static constexpr int PMAT = SH::KCA * SH::NV;                                       // W * Psi
+    static constexpr int HROW = SH::RT * WAVE;                                          // right-hand side h, [slot][lane]
+    static constexpr int VEC = 8 * SH::NV + 32;                                         // q, z, cost gradient, x_k, ref, scratch
+    static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC;
+};
+
+// c = Psi v (KC values) for a wave-uniform v, computed redundantly by every lane (broadcast LDS reads)
+template <class SH>
+__device__ __forceinline__ void factor_coords(const double *Psi, const double (&v)[SH::NV], double (&c)[SH::KCA]) {
+#pragma unroll
+    for (int a = 0; a < SH::KC; ++a) {
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < SH::NV; ++j) t += Psi[a * SH::NV + j] * v[j];
+        c[a] = t;
+    }
+}
+
+// G_row . v for the row that lives in (slot k, this lane): dense rows read their row of Gt,
+// factored rows read their kc-wide left factor and use c = Psi v.
+template <class SH, int K>
+__device__ __forceinline__ double row_dot(const double *Gt, const double *Hct, const double (&v)[SH::NV],
+                                          const double (&c)[SH::KCA], int lane) {
+    double t = 0.0;
+    if constexpr (K < SH::RD) {
+        const int r = lane + K * WAVE;
+#pragma unroll
+        for (int j = 0; j < SH::NV; ++j) t += Gt[j * SH::NDP + r] * v[j];
+    } else {
+        const int rc = lane + (K - SH::RD) * WAVE;
+#pragma unroll
+        for (int a = 0; a < SH::KC; ++a) t += Hct[a * SH::NCCP + rc] * c[a];
+    }
+    return t;
+}
+
+template <class SH>
+__device__ __forceinline__ bool slot_valid(int k, int lane, int nd, int ncc) {
+    return k < SH::RD ? (lane + k * WAVE < nd) : (lane + (k - SH::RD) * WAVE < ncc);
+}
+
+// One sweep over the DENSE rows of this lane for columns [J0, J1) of the lower triangle of G'DG.
+// FIRST also forms r_p and 1/s; LAST also accumulates G'(d.r_p) and G'lam.
+template <class SH, int J0, int J1, bool FIRST, bool LAST>
+__device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw, const double (&z)[SH::NV],
+                                              const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
+                                              double (&rs)[SH::RT], double &gap_l, double *red, double *sums, int lane, int nd) {
+    constexpr int NV = SH::NV, NDP = SH::NDP;
     constexpr int TRI = col_off<NV>(J1) - col_off<NV>(J0);
-    constexpr int CNT = TRI + (LAST ? 2 * NV + 1 : 0);
+    constexpr int CNT = TRI + (LAST ? 2 * NV : 0);
     constexpr int I0 = (FIRST || LAST) ? 0 : J0;        // first column this sweep has to load
     static_assert(!LAST || col_off<NV>(J1) == NV * (NV + 1) / 2, "the last block must end the triangle");
     double acc[CNT];
 #pragma unroll
     for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
 #pragma unroll
-    for (int k = 0; k < RPL; ++k) {
+    for (int k = 0; k < SH::RD; ++k) {
         const int r = lane + k * WAVE;
         double g[NV];
 #pragma unroll
-        for (int j = I0; j < NV; ++j) g[j] = Gt[j * NCP + r];
+        for (int j = I0; j < NV; ++j) g[j] = Gt[j * NDP + r];
         if (FIRST) {
             double gz = 0.0;
 #pragma unroll
             for (int j = 0; j < NV; ++j) gz += g[j] * z[j];
             rp[k] = gz + s[k] - hw[k * WAVE + lane];
-            rs[k] = (r < nc) ? fast_rcp(s[k]) : 0.0;
+            rs[k] = (r < nd) ? fast_rcp(s[k]) : 0.0;
+            gap_l += s[k] * lam[k];
         }
         const double d = lam[k] * rs[k];
 #pragma unroll
@@ -240,54 +292,91 @@ __device__ __forceinline__ void sweep_a(const double *Gt, const double *hw, cons
                 acc[TRI + i] += g[i] * t;
                 acc[TRI + NV + i] += g[i] * lam[k];
             }
-            acc[TRI + 2 * NV] += s[k] * lam[k];
         }
         row_fence();
     }
-    // totals: the triangle block lands at its packed position; the last block's vectors and the gap
-    // follow the triangle directly (col_off(J1) == NT there)
+    // the triangle block lands at its packed position; the last block's two vectors follow the triangle
     wave_reduce_to_lds<CNT>(acc, red, sums + col_off<NV>(J0), lane);
 }
 
-template <int NV, int RPL, int BI>
-__device__ __forceinline__ void sweep_a_all(const double *Gt, const double *hw, const double (&z)[NV],
-                                            const double (&s)[RPL], const double (&lam)[RPL], double (&rp)[RPL],
-                                            double (&rs)[RPL], double *red, double *sums, int lane, int nc) {
-    using BL = Blocks<NV>;
+template <class SH, int BI>
+__device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double *hw, const double (&z)[SH::NV],
+                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
+                                                  double (&rs)[SH::RT], double &gap_l, double *red, double *sums, int lane, int nd) {
+    using BL = Blocks<SH::NV>;
     if constexpr (BI < BL::n) {
-        sweep_a<NV, RPL, BL::b[BI], BL::b[BI + 1], BI == 0, BI == BL::n - 1>(Gt, hw, z, s, lam, rp, rs, red, sums, lane, nc);
-        sweep_a_all<NV, RPL, BI + 1>(Gt, hw, z, s, lam, rp, rs, red, sums, lane, nc);
+        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0, BI == BL::n - 1>(Gt, hw, z, s, lam, rp, rs, gap_l, red, sums, lane, nd);
+        sweep_a_dense_all<SH, BI + 1>(Gt, hw, z, s, lam, rp, rs, gap_l, red, sums, lane, nd);
     }
 }
 
-template <int NV, int RPL>
+// The FACTORED rows: kc-wide left factor, so W = Hc' D Hc has only KT entries; one pass.
+template <class SH>
+__device__ __forceinline__ void sweep_a_factored(const double *Hct, const double *hw, const double (&cz)[SH::KCA],
+                                                 const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
+                                                 double (&rs)[SH::RT], double &gap_l, double *red, double *csums, int lane, int ncc) {
+    constexpr int KC = SH::KC, KT = SH::KT, NCCP = SH::NCCP;
+    double acc[KT + 2 * KC];
+#pragma unroll
+    for (int i = 0; i < KT + 2 * KC; ++i) acc[i] = 0.0;
+#pragma unroll
+    for (int k = SH::RD; k < SH::RT; ++k) {
+        const int rc = lane + (k - SH::RD) * WAVE;
+        double hc[KC];
+        double gz = 0.0;
+#pragma unroll
+        for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * cz[a]; }
+        rp[k] = gz + s[k] - hw[k * WAVE + lane];
+        rs[k] = (rc < ncc) ? fast_rcp(s[k]) : 0.0;
+        gap_l += s[k] * lam[k];
+        const double d = lam[k] * rs[k];
+        const double t = d * rp[k];
+#pragma unroll
+        for (int a = 0; a < KC; ++a) {
+            const double dg = d * hc[a];
+#pragma unroll
+            for (int b2 = a; b2 < KC; ++b2) acc[col_off<KC>(a) + b2 - a] += dg * hc[b2];
+            acc[KT + a] += hc[a] * t;
+            acc[KT + KC + a] += hc[a] * lam[k];
+        }
+    }
+    wave_reduce_to_lds<KT + 2 * KC>(acc, red, csums, lane);
+}
+
+template <int NV, int RD, int KC, int RC>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
     const DeviceQP qp, const int variant_id, const int64_t B,
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
-    constexpr int NCP = RPL * WAVE;
-    constexpr int NT = NV * (NV + 1) / 2;
-    using WL = WaveLds<NV, RPL>;
+    using SH = Shape<NV, RD, KC, RC>;
+    using WL = WaveLds<SH>;
+    constexpr int RT = SH::RT, NDP = SH::NDP, NCCP = SH::NCCP, NT = SH::NT, KT = SH::KT, KCA = SH::KCA;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *Gt = smem;                         // [NV][NCP]
-    double *Hs = Gt + NV * NCP;                // [NV][NV]
+    double *Gt = smem;                         // [NV][NDP]
+    double *Hct = Gt + NV * NDP;               // [KC][NCCP]
+    double *Psi = Hct + KC * NCCP;             // [KC][NV]
+    double *Hs = Psi + KC * NV;                // [NV][NV]
     double *Hinv = Hs + NV * NV;               // [NV][NV]
     double *wbase = Hinv + NV * NV;
 
     const int tid = threadIdx.x;
     const int lane = tid & (WAVE - 1);
     const int wave = tid >> 6;
-    const int nx = qp.nx, nu = qp.nu, N = qp.N, nc = qp.nc;
+    const int nx = qp.nx, nu = qp.nu, N = qp.N, nd = qp.nd, ncc = qp.ncc, nc = qp.nc;
 
     // ---- stage the shared model once per workgroup (coalesced, L2-resident source)
-    for (int i = tid; i < NV * NCP; i += blockDim.x) Gt[i] = qp.Gt[i];
+    for (int i = tid; i < NV * NDP; i += blockDim.x) Gt[i] = qp.Gt[i];
+    for (int i = tid; i < KC * NCCP; i += blockDim.x) Hct[i] = qp.Hct[i];
+    for (int i = tid; i < KC * NV; i += blockDim.x) Psi[i] = qp.Psi[i];
     for (int i = tid; i < NV * NV; i += blockDim.x) { Hs[i] = qp.Hs[i]; Hinv[i] = qp.Hinv[i]; }
     __syncthreads();
 
     double *red = wbase + wave * WL::TOTAL;       // transposition tile / refinement workspace
-    double *sums = red + WL::BIG;                 // reduced totals: triangle (column-major packed), vectors, gap
-    double *hw = sums + WL::SUMS;                 // h, [slot][lane]
+    double *sums = red + WL::BIG;                 // dense totals: triangle (column-major packed), two vectors
+    double *csums = sums + WL::SUMS;              // factored-block totals: W (packed), two kc-vectors
+    double *Pm = csums + WL::CSUMS;               // [KC][NV] W * Psi
+    double *hw = Pm + WL::PMAT;                   // h, [slot][lane]
     double *vec = hw + WL::HROW;
     double *qv = vec;                 // [NV] linear term
     double *zv = vec + NV;            // [NV] current z (wave-uniform copy)
@@ -328,15 +417,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
         }
         double hn = 1.0;
 #pragma unroll
-        for (int k = 0; k < RPL; ++k) {
-            const int r = lane + k * WAVE;
-            double v = 1.0;
-            if (r < nc) {
-                v = qp.g0s[r];
-                for (int c = 0; c < nx; ++c) v += qp.Es[r * nx + c] * xin[c];
-                hn = fmax(hn, fabs(v));
-            }
-            hw[k * WAVE + lane] = v;
+        for (int k = 0; k < RT; ++k) {
+            const int sl = k * WAVE + lane;
+            double v = qp.g0p[sl];
+            for (int c = 0; c < nx; ++c) v += qp.Esp[sl * nx + c] * xin[c];
+            if (slot_valid<SH>(k, lane, nd, ncc)) hn = fmax(hn, fabs(v));
+            hw[sl] = v;
         }
         hn = wave_max(hn);
         wave_lds_fence();
@@ -353,17 +439,21 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
 #pragma unroll
         for (int j = 0; j < NV; ++j) { z[j] = zv[j]; qn = fmax(qn, fabs(qv[j])); }
 
-        double s[RPL], lam[RPL];
+        double s[RT], lam[RT];
         double smin = INFINITY;
-#pragma unroll
-        for (int k = 0; k < RPL; ++k) {
-            const int r = lane + k * WAVE;
-            double gz = 0.0;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) gz += Gt[j * NCP + r] * z[j];
-            s[k] = hw[k * WAVE + lane] - gz;
-            lam[k] = 0.0;
-            if (r < nc) smin = fmin(smin, s[k]);
+        {
+            double cz[KCA];
+            factor_coords<SH>(Psi, z, cz);
+            // unrolled by the template recursion below
+            auto init_slot = [&](auto kc_) {
+                constexpr int k = decltype(kc_)::value;
+                const double gz = row_dot<SH, k>(Gt, Hct, z, cz, lane);
+                s[k] = hw[k * WAVE + lane] - gz;
+                lam[k] = 0.0;
+                if (slot_valid<SH>(k, lane, nd, ncc)) smin = fmin(smin, s[k]);
+            };
+            [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (init_slot(std::integral_constant<int, Ks>{}), ...); }
+            (std::make_integer_sequence<int, RT>{});
         }
         smin = wave_min(smin);
         STAMP(0);
@@ -378,8 +468,8 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                 const double viol = -smin;
                 const double fl = 0.1 * fmax(viol, 1.0);
 #pragma unroll
-                for (int k = 0; k < RPL; ++k) {
-                    const bool valid = lane + k * WAVE < nc;
+                for (int k = 0; k < RT; ++k) {
+                    const bool valid = slot_valid<SH>(k, lane, nd, ncc);
                     s[k] = valid ? fmax(s[k], fl) : 1.0;
                     lam[k] = valid ? 1.0 : 0.0;
                 }
@@ -394,17 +484,44 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             bool want_polish = false;
             for (; it < qp.max_iter; ++it) {
                 it_done = it;
-                // ---- sweeps A: residuals, 1/s, lower triangle of G'DG by column blocks, G'(d.rp), G'lam, gap
-                double rp[RPL], rs[RPL];
-                sweep_a_all<NV, RPL, 0>(Gt, hw, z, s, lam, rp, rs, red, sums, lane, nc);
-                STAMP(1);
+                // ---- sweeps A: residuals, 1/s, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam
+                double rp[RT], rs[RT];
+                double gap_l = 0.0;
+                if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, z, s, lam, rp, rs, gap_l, red, sums, lane, nd);
+                if constexpr (KC > 0) {
+                    double cz[KCA];
+                    factor_coords<SH>(Psi, z, cz);
+                    sweep_a_factored<SH>(Hct, hw, cz, s, lam, rp, rs, gap_l, red, csums, lane, ncc);
+                    // fold the factored block into the dense totals: P = W Psi now, Psi' P when the rows are loaded
+                    for (int idx = lane; idx < KC * NV; idx += WAVE) {
+                        const int a = idx / NV, j = idx - a * NV;
+                        double v = 0.0;
+#pragma unroll
+                        for (int b2 = 0; b2 < KC; ++b2) {
+                            const int lo = a < b2 ? a : b2, hi2 = a < b2 ? b2 : a;
+                            v += csums[lo * KC - lo * (lo - 1) / 2 + hi2 - lo] * Psi[b2 * NV + j];
+                        }
+                        Pm[idx] = v;
+                    }
+                    double v1 = 0.0, gl = 0.0;
+                    if (lane < NV) {
+                        v1 = (RD > 0) ? sums[NT + lane] : 0.0;
+                        gl = (RD > 0) ? sums[NT + NV + lane] : 0.0;
+#pragma unroll
+                        for (int a = 0; a < KC; ++a) { v1 += Psi[a * NV + lane] * csums[KT + a]; gl += Psi[a * NV + lane] * csums[KT + KC + a]; }
+                    }
+                    wave_lds_fence();
+                    if (lane < NV) { sums[NT + lane] = v1; sums[NT + NV + lane] = gl; }
+                    wave_lds_fence();
+                }
                 double rpn = 0.0, lmax = 0.0;
 #pragma unroll
-                for (int k = 0; k < RPL; ++k) { rpn = fmax(rpn, fabs(rp[k])); lmax = fmax(lmax, lam[k]); }
+                for (int k = 0; k < RT; ++k) { rpn = fmax(rpn, fabs(rp[k])); lmax = fmax(lmax, lam[k]); }
                 rpn = wave_max(rpn);
                 lmax = wave_max(lmax);
-                const double gap = sums[NT + 2 * NV];
+                const double gap = wave_sum(gap_l);
                 const double mu = gap / ncd;
+                STAMP(1);
                 // cost gradient cg = Hs z + q (lane i computes entry i)
                 if (lane < NV) {
                     double v = 0.0;
@@ -430,7 +547,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                     // Farkas-type certificate: lam blows up, G'lam -> 0, h'lam < 0
                     double hl = 0.0;
 #pragma unroll
-                    for (int k = 0; k < RPL; ++k) hl += hw[k * WAVE + lane] * lam[k];
+                    for (int k = 0; k < RT; ++k) hl += hw[k * WAVE + lane] * lam[k];
                     hl = wave_sum(hl);
                     double gn = 0.0;
 #pragma unroll
@@ -448,7 +565,12 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
 #pragma unroll
                         for (int j = 0; j < NV; ++j) {
                             const int lo = li < j ? li : j, hi2 = li < j ? j : li;
-                            const double v = Hs[li * NV + j] + sums[lo * NV - lo * (lo - 1) / 2 + hi2 - lo] + (li == j ? shift : 0.0);
+                            double v = Hs[li * NV + j] + (li == j ? shift : 0.0);
+                            if constexpr (RD > 0) v += sums[lo * NV - lo * (lo - 1) / 2 + hi2 - lo];
+                            if constexpr (KC > 0) {
+#pragma unroll
+                                for (int a = 0; a < KC; ++a) v += Psi[a * NV + li] * Pm[a * NV + j];
+                            }
                             mrow[j] = (lane < NV) ? v : 0.0;
                         }
                         rhs_i = (lane < NV) ? -cgv[li] - sums[NT + li] : 0.0;
@@ -461,81 +583,117 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                             // non-positive pivot from cancellation: retry once with a 1e-13 * trace shift
                             double trc = 0.0;
 #pragma unroll
-                            for (int i = 0; i < NV; ++i) trc += Hs[i * NV + i] + sums[col_off<NV>(i)];
-                            shift = 1e-13 * trc;
+                            for (int i = 0; i < NV; ++i) trc += Hs[i * NV + i];
+                            shift = 1e-13 * (trc + lmax);
                         }
                     }
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
                 }
                 STAMP(3);
                 // ---- sweep B: affine step statistics and the corrector's G' products
-                double wprod[RPL];
-                double rho_aff = 0.0;
+                double wprod[RT];
+                double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
+                double v2 = 0.0, v3 = 0.0;          // lane i < NV: entries i of G'(dsa.dla/s) and G'(1/s)
                 {
-                    double accb[2 * NV + 2];
-#pragma unroll
-                    for (int i = 0; i < 2 * NV + 2; ++i) accb[i] = 0.0;
-#pragma unroll
-                    for (int k = 0; k < RPL; ++k) {
-                        const int r = lane + k * WAVE;
-                        const bool valid = r < nc;
-                        double g[NV];
-                        double gdz = 0.0;
-#pragma unroll
-                        for (int j = 0; j < NV; ++j) { g[j] = Gt[j * NCP + r]; gdz += g[j] * dz[j]; }
+                    double cdz[KCA];
+                    if constexpr (KC > 0) factor_coords<SH>(Psi, dz, cdz);
+                    auto step_stats = [&](int k, bool valid, double gdz) {
                         const double dsa = valid ? (-rp[k] - gdz) : 0.0;
                         const double dla = valid ? (-lam[k] - lam[k] * rs[k] * dsa) : 0.0;
                         const double rl = valid ? fast_rcp(lam[k]) : 0.0;
                         rho_aff = fmax(rho_aff, fmax(-dsa * rs[k], -dla * rl));
                         wprod[k] = dsa * dla;
-                        accb[2 * NV] += s[k] * dla + lam[k] * dsa;
-                        accb[2 * NV + 1] += wprod[k];
-                        const double c1 = wprod[k] * rs[k];
+                        sb1 += s[k] * dla + lam[k] * dsa;
+                        sb2 += wprod[k];
+                    };
+                    if constexpr (RD > 0) {
+                        double accb[2 * NV];
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) { accb[j] += g[j] * c1; accb[NV + j] += g[j] * rs[k]; }
-                        row_fence();
+                        for (int i = 0; i < 2 * NV; ++i) accb[i] = 0.0;
+#pragma unroll
+                        for (int k = 0; k < RD; ++k) {
+                            const int r = lane + k * WAVE;
+                            double g[NV];
+                            double gdz = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) { g[j] = Gt[j * NDP + r]; gdz += g[j] * dz[j]; }
+                            step_stats(k, r < nd, gdz);
+                            const double c1 = wprod[k] * rs[k];
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) { accb[j] += g[j] * c1; accb[NV + j] += g[j] * rs[k]; }
+                            row_fence();
+                        }
+                        wave_reduce_to_lds<2 * NV>(accb, red, sums + NT, lane);   // overwrites G'(d.rp), G'lam (consumed)
+                    }
+                    if constexpr (KC > 0) {
+                        double accc[2 * KC];
+#pragma unroll
+                        for (int i = 0; i < 2 * KC; ++i) accc[i] = 0.0;
+#pragma unroll
+                        for (int k = RD; k < RT; ++k) {
+                            const int rc = lane + (k - RD) * WAVE;
+                            double hc[KC];
+                            double gdz = 0.0;
+#pragma unroll
+                            for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gdz += hc[a] * cdz[a]; }
+                            step_stats(k, rc < ncc, gdz);
+                            const double c1 = wprod[k] * rs[k];
+#pragma unroll
+                            for (int a = 0; a < KC; ++a) { accc[a] += hc[a] * c1; accc[KC + a] += hc[a] * rs[k]; }
+                        }
+                        wave_reduce_to_lds<2 * KC>(accc, red, csums + KT, lane);
                     }
                     rho_aff = wave_max(rho_aff);
-                    wave_reduce_to_lds<2 * NV + 2>(accb, red, sums + NT, lane);   // overwrites G'(d.rp), G'lam (consumed)
+                    sb1 = wave_sum(sb1);
+                    sb2 = wave_sum(sb2);
+                    if (lane < NV) {
+                        if constexpr (RD > 0) { v2 = sums[NT + lane]; v3 = sums[NT + NV + lane]; }
+                        if constexpr (KC > 0) {
+#pragma unroll
+                            for (int a = 0; a < KC; ++a) { v2 += Psi[a * NV + lane] * csums[KT + a]; v3 += Psi[a * NV + lane] * csums[KT + KC + a]; }
+                        }
+                    }
                 }
                 STAMP(4);
                 const double aaff = rho_aff > 1.0 ? 1.0 / rho_aff : 1.0;
-                const double mu_aff = (gap + aaff * sums[NT + 2 * NV] + aaff * aaff * sums[NT + 2 * NV + 1]) / ncd;
+                const double mu_aff = (gap + aaff * sb1 + aaff * aaff * sb2) / ncd;
                 double sigma = mu_aff / mu;
                 sigma = fmin(sigma * sigma * sigma, 1.0);
                 const double smu = sigma * mu;
                 {
-                    const int li = lane < NV ? lane : 0;
-                    double bb = (lane < NV) ? rhs_i + sums[NT + li] - smu * sums[NT + NV + li] : 0.0;
+                    double bb = (lane < NV) ? rhs_i + v2 - smu * v3 : 0.0;
                     rows_forward<NV>(mrow, bb, lane);
                     rows_backsub<NV>(mrow, bb, mdinv, dz);
                 }
                 STAMP(5);
                 // ---- sweep D: final direction, step length, update
-                double ds[RPL];
+                double ds[RT];
                 double om = (1.0 - aaff) * (1.0 - aaff);
                 om = fmin(fmax(om, 1e-4), 1e-2);
                 const double tau = 1.0 - om;
                 double rho = 0.0;
-#pragma unroll
-                for (int k = 0; k < RPL; ++k) {
-                    const int r = lane + k * WAVE;
-                    const bool valid = r < nc;
-                    double gdz = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NV; ++j) gdz += Gt[j * NCP + r] * dz[j];
-                    ds[k] = valid ? (-rp[k] - gdz) : 0.0;
-                    const double rc = s[k] * lam[k] + wprod[k] - smu;
-                    const double dl = valid ? (-(rc + lam[k] * ds[k]) * rs[k]) : 0.0;
-                    const double rl = valid ? fast_rcp(lam[k]) : 0.0;
-                    rho = fmax(rho, fmax(-ds[k] * rs[k], -dl * rl));
-                    wprod[k] = dl;                        // the product is consumed; keep dl in its place
-                    row_fence();
+                {
+                    double cdz[KCA];
+                    if constexpr (KC > 0) factor_coords<SH>(Psi, dz, cdz);
+                    auto step_row = [&](auto kc_) {
+                        constexpr int k = decltype(kc_)::value;
+                        const bool valid = slot_valid<SH>(k, lane, nd, ncc);
+                        const double gdz = row_dot<SH, k>(Gt, Hct, dz, cdz, lane);
+                        ds[k] = valid ? (-rp[k] - gdz) : 0.0;
+                        const double rc = s[k] * lam[k] + wprod[k] - smu;
+                        const double dl = valid ? (-(rc + lam[k] * ds[k]) * rs[k]) : 0.0;
+                        const double rl = valid ? fast_rcp(lam[k]) : 0.0;
+                        rho = fmax(rho, fmax(-ds[k] * rs[k], -dl * rl));
+                        wprod[k] = dl;                        // the product is consumed; keep dl in its place
+                        if constexpr (k < RD) row_fence();
+                    };
+                    [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (step_row(std::integral_constant<int, Ks>{}), ...); }
+                    (std::make_integer_sequence<int, RT>{});
                 }
                 rho = wave_max(rho);
                 const double alpha = rho > tau ? tau / rho : 1.0;
 #pragma unroll
-                for (int k = 0; k < RPL; ++k) { s[k] += alpha * ds[k]; lam[k] += alpha * wprod[k]; }
+                for (int k = 0; k < RT; ++k) { s[k] += alpha * ds[k]; lam[k] += alpha * wprod[k]; }
 #pragma unroll
                 for (int j = 0; j < NV; ++j) z[j] += alpha * dz[j];
 #pragma unroll
@@ -547,188 +705,206 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             if (!want_polish) break;
             // ------------------------------------------------ active-set refinement
             bool ok = false;
-                {
-                    // workspace carved from the (now idle) transposition tile
-                    double *T = red;                          // [NV][WCAP]
-                    double *S = T + NV * WCAP;                // [WCAP][WCAP+1]
-                    double *yv = S + WCAP * (WCAP + 1);       // [WCAP]
-                    double *dyv = yv + WCAP;                  // [WCAP]
-                    int *Widx = reinterpret_cast<int *>(dyv + WCAP);   // [WCAP] (+ spare)
-                    bool inW[RPL];
-                    double yall[RPL];
+            {
+                // workspace carved from the (now idle) transposition tile
+                double *GW = red;                         // [WCAP][NV]  rows of the working set, expanded
+                double *T = GW + WCAP * NV;               // [NV][WCAP]
+                double *S = T + NV * WCAP;                // [WCAP][WCAP+1]
+                double *yv = S + WCAP * (WCAP + 1);       // [WCAP]
+                double *dyv = yv + WCAP;                  // [WCAP]
+                int *Widx = reinterpret_cast<int *>(dyv + WCAP);   // [WCAP] global row ids
+                bool inW[RT];
+                double yall[RT];
 #pragma unroll
-                    for (int k = 0; k < RPL; ++k) { inW[k] = (lane + k * WAVE < nc) && (lam[k] > s[k]); yall[k] = lam[k]; }
-                    double zp[NV];
+                for (int k = 0; k < RT; ++k) { inW[k] = slot_valid<SH>(k, lane, nd, ncc) && (lam[k] > s[k]); yall[k] = lam[k]; }
+                double zp[NV];
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) zp[j] = z[j];
-                    for (int round = 0; round < 6 && !ok; ++round) {
-                        // compact the working set: W[0..m)
-                        int m = 0;
+                for (int j = 0; j < NV; ++j) zp[j] = z[j];
+                for (int round = 0; round < 6 && !ok; ++round) {
+                    // compact the working set: W[0..m)
+                    int m = 0;
 #pragma unroll
-                        for (int k = 0; k < RPL; ++k) {
-                            const unsigned long long bal = __ballot(inW[k]);
-                            const int pos = m + __popcll(bal & ((1ull << lane) - 1ull));
-                            if (inW[k] && pos < WCAP) { Widx[pos] = lane + k * WAVE; yv[pos] = yall[k]; }
-                            m += __popcll(bal);
+                    for (int k = 0; k < RT; ++k) {
+                        const unsigned long long bal = __ballot(inW[k]);
+                        const int pos = m + __popcll(bal & ((1ull << lane) - 1ull));
+                        const int gid = k < RD ? lane + k * WAVE : nd + lane + (k - RD) * WAVE;
+                        if (inW[k] && pos < WCAP) { Widx[pos] = gid; yv[pos] = yall[k]; }
+                        m += __popcll(bal);
+                    }
+                    wave_lds_fence();
+                    if (m > WCAP) break;
+                    if (m == 0) {
+                        if (lane < NV) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) v -= Hinv[lane * NV + j] * qv[j];
+                            tv[lane] = v;
                         }
                         wave_lds_fence();
-                        if (m > WCAP) break;
-                        if (m == 0) {
-                            if (lane < NV) {
-                                double v = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v -= Hinv[lane * NV + j] * qv[j];
+                        for (int j = 0; j < NV; ++j) zp[j] = tv[j];
+                    } else {
+                        // expand the working rows: dense rows are copied, factored rows are Hc_r * Psi
+                        for (int idx = lane; idx < m * NV; idx += WAVE) {
+                            const int k = idx / NV, j = idx - k * NV;
+                            const int r = Widx[k];
+                            double v = 0.0;
+                            if (r < nd) {
+                                v = Gt[j * NDP + r];
+                            } else {
+                                if constexpr (KC > 0) {
+#pragma unroll
+                                    for (int a = 0; a < KC; ++a) v += Hct[a * NCCP + (r - nd)] * Psi[a * NV + j];
+                                }
+                            }
+                            GW[idx] = v;
+                        }
+                        wave_lds_fence();
+                        // T = Hinv G_W'  (entry (i,k): i = idx / m, k = idx % m)
+                        for (int idx = lane; idx < NV * m; idx += WAVE) {
+                            const int i = idx / m, k = idx - i * m;
+                            double v = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) v += Hinv[i * NV + j] * GW[k * NV + j];
+                            T[i * WCAP + k] = v;
+                        }
+                        wave_lds_fence();
+                        // S = G_W T (+ delta I)
+                        for (int idx = lane; idx < m * m; idx += WAVE) {
+                            const int a = idx / m, c2 = idx - a * m;
+                            double v = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) v += GW[a * NV + j] * T[j * WCAP + c2];
+                            S[a * (WCAP + 1) + c2] = v;
+                        }
+                        wave_lds_fence();
+                        double dmax = 0.0;
+                        if (lane < m) dmax = S[lane * (WCAP + 1) + lane];
+                        dmax = wave_max(dmax);
+                        if (lane < m) S[lane * (WCAP + 1) + lane] += 1e-11 * dmax;
+                        wave_lds_fence();
+                        // Cholesky of S in LDS, right-looking; lane a owns row a
+                        bool spd = true;
+                        for (int j = 0; j < m; ++j) {
+                            const double pjj = S[j * (WCAP + 1) + j];
+                            if (!(pjj > 0.0)) { spd = false; break; }
+                            const double piv = sqrt(pjj);
+                            double lij = 0.0;
+                            if (lane > j && lane < m) lij = S[lane * (WCAP + 1) + j] / piv;
+                            wave_lds_fence();
+                            if (lane == j) S[j * (WCAP + 1) + j] = piv;
+                            if (lane > j && lane < m) S[lane * (WCAP + 1) + j] = lij;
+                            wave_lds_fence();
+                            // trailing update: row `lane`, columns j+1..lane
+                            if (lane > j && lane < m) {
+                                for (int c2 = j + 1; c2 <= lane; ++c2)
+                                    S[lane * (WCAP + 1) + c2] -= lij * S[c2 * (WCAP + 1) + j];
+                            }
+                            wave_lds_fence();
+                        }
+                        if (!spd) break;
+                        // four proximal Newton steps on the KKT system of the working set
+                        for (int stp = 0; stp < 4; ++stp) {
+                            // r1 = Hs zp + q + G_W' y   (lane i -> entry i)
+                            if (lane < NV) {
+                                double v = qv[lane];
+#pragma unroll
+                                for (int j = 0; j < NV; ++j) v += Hs[lane * NV + j] * zp[j];
+                                for (int k = 0; k < m; ++k) v += GW[k * NV + lane] * yv[k];
                                 tv[lane] = v;
                             }
                             wave_lds_fence();
-#pragma unroll
-                            for (int j = 0; j < NV; ++j) zp[j] = tv[j];
-                        } else {
-                            // T = Hinv G_W'  (entry (i,k): i = idx / m, k = idx % m)
-                            for (int idx = lane; idx < NV * m; idx += WAVE) {
-                                const int i = idx / m, k = idx - i * m;
-                                const int r = Widx[k];
+                            // t1 = Hinv r1
+                            if (lane < NV) {
                                 double v = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v += Hinv[i * NV + j] * Gt[j * NCP + r];
-                                T[i * WCAP + k] = v;
+                                for (int j = 0; j < NV; ++j) v += Hinv[lane * NV + j] * tv[j];
+                                uv[lane] = v;
                             }
                             wave_lds_fence();
-                            // S = G_W T (+ delta I)
-                            for (int idx = lane; idx < m * m; idx += WAVE) {
-                                const int a = idx / m, c2 = idx - a * m;
-                                const int r = Widx[a];
-                                double v = 0.0;
+                            // dy rhs: (G_W zp - h_W) - G_W t1
+                            if (lane < m) {
+                                const int r = Widx[lane];
+                                double gz = 0.0, gt = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v += Gt[j * NCP + r] * T[j * WCAP + c2];
-                                S[a * (WCAP + 1) + c2] = v;
+                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * NV + j]; gz += g * zp[j]; gt += g * uv[j]; }
+                                const int sl = r < nd ? r : NDP + (r - nd);
+                                dyv[lane] = gz - hw[sl] - gt;
                             }
                             wave_lds_fence();
-                            double dmax = 0.0;
-                            if (lane < m) dmax = S[lane * (WCAP + 1) + lane];
-                            dmax = wave_max(dmax);
-                            if (lane < m) S[lane * (WCAP + 1) + lane] += 1e-11 * dmax;
-                            wave_lds_fence();
-                            // Cholesky of S in LDS, right-looking; lane a owns row a
-                            bool spd = true;
+                            // forward / backward substitution with L (in S), m sequential steps each
                             for (int j = 0; j < m; ++j) {
-                                const double pjj = S[j * (WCAP + 1) + j];
-                                if (!(pjj > 0.0)) { spd = false; break; }
-                                const double piv = sqrt(pjj);
-                                double lij = 0.0;
-                                if (lane > j && lane < m) lij = S[lane * (WCAP + 1) + j] / piv;
+                                const double vj = dyv[j] / S[j * (WCAP + 1) + j];
                                 wave_lds_fence();
-                                if (lane == j) S[j * (WCAP + 1) + j] = piv;
-                                if (lane > j && lane < m) S[lane * (WCAP + 1) + j] = lij;
-                                wave_lds_fence();
-                                // trailing update: row `lane`, columns j+1..lane
-                                if (lane > j && lane < m) {
-                                    for (int c2 = j + 1; c2 <= lane; ++c2)
-                                        S[lane * (WCAP + 1) + c2] -= lij * S[c2 * (WCAP + 1) + j];
-                                }
+                                if (lane == j) dyv[j] = vj;
+                                if (lane > j && lane < m) dyv[lane] -= S[lane * (WCAP + 1) + j] * vj;
                                 wave_lds_fence();
                             }
-                            if (!spd) break;
-                            // four proximal Newton steps on the KKT system of the working set
-                            for (int stp = 0; stp < 4; ++stp) {
-                                // r1 = Hs zp + q + G_W' y   (lane i -> entry i)
-                                if (lane < NV) {
-                                    double v = qv[lane];
-#pragma unroll
-                                    for (int j = 0; j < NV; ++j) v += Hs[lane * NV + j] * zp[j];
-                                    for (int k = 0; k < m; ++k) v += Gt[lane * NCP + Widx[k]] * yv[k];
-                                    tv[lane] = v;
-                                }
+                            for (int j = m - 1; j >= 0; --j) {
+                                const double vj = dyv[j] / S[j * (WCAP + 1) + j];
                                 wave_lds_fence();
-                                // t1 = Hinv r1
-                                if (lane < NV) {
-                                    double v = 0.0;
-#pragma unroll
-                                    for (int j = 0; j < NV; ++j) v += Hinv[lane * NV + j] * tv[j];
-                                    uv[lane] = v;
-                                }
-                                wave_lds_fence();
-                                // dy rhs: (G_W zp - h_W) - G_W t1
-                                if (lane < m) {
-                                    const int r = Widx[lane];
-                                    double gz = 0.0, gt = 0.0;
-#pragma unroll
-                                    for (int j = 0; j < NV; ++j) { const double g = Gt[j * NCP + r]; gz += g * zp[j]; gt += g * uv[j]; }
-                                    dyv[lane] = gz - hw[(r >> 6) * WAVE + (r & 63)] - gt;
-                                }
-                                wave_lds_fence();
-                                // forward / backward substitution with L (in S), m sequential steps each
-                                for (int j = 0; j < m; ++j) {
-                                    const double vj = dyv[j] / S[j * (WCAP + 1) + j];
-                                    wave_lds_fence();
-                                    if (lane == j) dyv[j] = vj;
-                                    if (lane > j && lane < m) dyv[lane] -= S[lane * (WCAP + 1) + j] * vj;
-                                    wave_lds_fence();
-                                }
-                                for (int j = m - 1; j >= 0; --j) {
-                                    const double vj = dyv[j] / S[j * (WCAP + 1) + j];
-                                    wave_lds_fence();
-                                    if (lane == j) dyv[j] = vj;
-                                    if (lane < j) dyv[lane] -= S[j * (WCAP + 1) + lane] * vj;
-                                    wave_lds_fence();
-                                }
-                                // zp -= t1 + T dy ; y += dy
-#pragma unroll
-                                for (int j = 0; j < NV; ++j) {
-                                    double v = uv[j];
-                                    for (int k = 0; k < m; ++k) v += T[j * WCAP + k] * dyv[k];
-                                    zp[j] -= v;
-                                }
-                                if (lane < m) yv[lane] += dyv[lane];
+                                if (lane == j) dyv[j] = vj;
+                                if (lane < j) dyv[lane] -= S[j * (WCAP + 1) + lane] * vj;
                                 wave_lds_fence();
                             }
+                            // zp -= t1 + T dy ; y += dy
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) {
+                                double v = uv[j];
+                                for (int k = 0; k < m; ++k) v += T[j * WCAP + k] * dyv[k];
+                                zp[j] -= v;
+                            }
+                            if (lane < m) yv[lane] += dyv[lane];
+                            wave_lds_fence();
                         }
-                        // ---- verify: primal feasibility on all rows, sign of y on W
-                        double ymax = 1.0;
-                        for (int k = 0; k < m; ++k) ymax = fmax(ymax, fabs(yv[k]));
-                        int nviol = 0, nneg = 0, nloose = 0;
-                        double rr[RPL];
-                        {
-                            int mm = 0;
+                    }
+                    // ---- verify: primal feasibility on all rows, sign of y on W
+                    double ymax = 1.0;
+                    for (int k = 0; k < m; ++k) ymax = fmax(ymax, fabs(yv[k]));
+                    int nviol = 0, nneg = 0, nloose = 0;
+                    double rr[RT];
+                    {
+                        double czp[KCA];
+                        if constexpr (KC > 0) factor_coords<SH>(Psi, zp, czp);
+                        int mm = 0;
+                        auto check_slot = [&](auto kc_) {
+                            constexpr int k = decltype(kc_)::value;
+                            const double gz = row_dot<SH, k>(Gt, Hct, zp, czp, lane);
+                            const double hk = hw[k * WAVE + lane];
+                            rr[k] = gz - hk;
+                            const unsigned long long bal = __ballot(inW[k]);
+                            const int pos = mm + __popcll(bal & ((1ull << lane) - 1ull));
+                            mm += __popcll(bal);
+                            const bool valid = slot_valid<SH>(k, lane, nd, ncc);
+                            const double hi = fmax(fabs(hk), 1.0);
+                            bool viol = valid && !inW[k] && rr[k] > 1e-12 * hi;
+                            // a working-set row that is not on its bound: the Newton steps have not converged
+                            const bool loose = inW[k] && fabs(rr[k]) > 1e-11 * hi;
+                            bool neg = false;
+                            if (inW[k]) { yall[k] = yv[pos < WCAP ? pos : 0]; neg = yall[k] < -1e-10 * ymax; }
+                            nviol += __popcll(__ballot(viol));
+                            nneg += __popcll(__ballot(neg));
+                            nloose += __popcll(__ballot(loose));
+                            if (neg) { inW[k] = false; yall[k] = 0.0; }
+                            if (viol) { inW[k] = true; yall[k] = 0.0; }
+                        };
+                        [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (check_slot(std::integral_constant<int, Ks>{}), ...); }
+                        (std::make_integer_sequence<int, RT>{});
+                    }
+                    wave_lds_fence();
+                    if (nloose != 0) break;
+                    if (nviol == 0 && nneg == 0) {
+                        ok = true;
 #pragma unroll
-                            for (int k = 0; k < RPL; ++k) {
-                                const int r = lane + k * WAVE;
-                                double gz = 0.0;
+                        for (int j = 0; j < NV; ++j) z[j] = zp[j];
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) gz += Gt[j * NCP + r] * zp[j];
-                                const double hk = hw[k * WAVE + lane];
-                                rr[k] = gz - hk;
-                                const unsigned long long bal = __ballot(inW[k]);
-                                const int pos = mm + __popcll(bal & ((1ull << lane) - 1ull));
-                                mm += __popcll(bal);
-                                const bool valid = r < nc;
-                                const double hi = fmax(fabs(hk), 1.0);
-                                bool viol = valid && !inW[k] && rr[k] > 1e-12 * hi;
-                                // a working-set row that is not on its bound: the Newton steps have not converged
-                                const bool loose = inW[k] && fabs(rr[k]) > 1e-11 * hi;
-                                bool neg = false;
-                                if (inW[k]) { yall[k] = yv[pos]; neg = yall[k] < -1e-10 * ymax; }
-                                nviol += __popcll(__ballot(viol));
-                                nneg += __popcll(__ballot(neg));
-                                nloose += __popcll(__ballot(loose));
-                                if (neg) { inW[k] = false; yall[k] = 0.0; }
-                                if (viol) { inW[k] = true; yall[k] = 0.0; }
-                            }
-                        }
-                        wave_lds_fence();
-                        if (nloose != 0) break;
-                        if (nviol == 0 && nneg == 0) {
-                            ok = true;
-#pragma unroll
-                            for (int j = 0; j < NV; ++j) z[j] = zp[j];
-#pragma unroll
-                            for (int k = 0; k < RPL; ++k) {
-                                lam[k] = inW[k] ? fmax(yall[k], 0.0) : 0.0;
-                                s[k] = rr[k] < 0.0 ? -rr[k] : 0.0;
-                            }
+                        for (int k = 0; k < RT; ++k) {
+                            lam[k] = inW[k] ? fmax(yall[k], 0.0) : 0.0;
+                            s[k] = rr[k] < 0.0 ? -rr[k] : 0.0;
                         }
                     }
                 }
+            }
             STAMP(7);
             if (ok) { st = TMPC_STATUS_OPTIMAL; break; }
             if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
@@ -737,14 +913,15 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             if (st == TMPC_STATUS_MAX_ITER) {
                 // iteration cap: if the iterate still violates the constraints, call it infeasible
                 double viol = 0.0;
-#pragma unroll
-                for (int k = 0; k < RPL; ++k) {
-                    const int r = lane + k * WAVE;
-                    double gz = 0.0;
-#pragma unroll
-                    for (int j = 0; j < NV; ++j) gz += Gt[j * NCP + r] * z[j];
-                    if (r < nc) viol = fmax(viol, gz - hw[k * WAVE + lane]);
-                }
+                double cz[KCA];
+                if constexpr (KC > 0) factor_coords<SH>(Psi, z, cz);
+                auto viol_slot = [&](auto kc_) {
+                    constexpr int k = decltype(kc_)::value;
+                    const double gz = row_dot<SH, k>(Gt, Hct, z, cz, lane);
+                    if (slot_valid<SH>(k, lane, nd, ncc)) viol = fmax(viol, gz - hw[k * WAVE + lane]);
+                };
+                [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (viol_slot(std::integral_constant<int, Ks>{}), ...); }
+                (std::make_integer_sequence<int, RT>{});
                 viol = wave_max(viol);
                 if (viol > 1e-6 * hn) st = TMPC_STATUS_INFEASIBLE;
             }
@@ -793,22 +970,24 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
     }
 }
 
-template <int NV, int RPL>
+template <class SH>
 constexpr size_t kernel_lds_bytes() {
-    return sizeof(double) * (static_cast<size_t>(NV) * RPL * WAVE + 2 * NV * NV + WAVES_PER_BLOCK * WaveLds<NV, RPL>::TOTAL);
+    return sizeof(double) * (static_cast<size_t>(SH::NV) * SH::NDP + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
+                             WAVES_PER_BLOCK * WaveLds<SH>::TOTAL);
 }
 
-template <int NV, int RPL>
+template <int NV, int RD, int KC, int RC>
 hipError_t launch_one(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
-    constexpr size_t lds = kernel_lds_bytes<NV, RPL>();
+    constexpr size_t lds = kernel_lds_bytes<Shape<NV, RD, KC, RC>>();
+    static_assert(lds <= 160 * 1024, "shape does not fit the 160 KiB LDS of a CU");
     // > 64 KiB of dynamic LDS needs the opt-in once per device and instantiation
     static bool attr_set[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, RPL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, RD, KC, RC>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
@@ -817,45 +996,51 @@ hipError_t launch_one(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     const int64_t cap = static_cast<int64_t>(n_cu) * 4;     // a few workgroups per CU, grid-stride over the batch
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((solve_kernel<NV, RPL>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WAVES_PER_BLOCK), lds, stream,
+    hipLaunchKernelGGL((solve_kernel<NV, RD, KC, RC>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WAVES_PER_BLOCK), lds, stream,
                        qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
     return hipGetLastError();
 }
 
 }  // namespace
 
-size_t lds_bytes(int nvp, int rpl) {
-#define TMPC_LDS(NVV, RPLV) if (nvp == NVV && rpl == RPLV) return kernel_lds_bytes<NVV, RPLV>();
-    TMPC_LDS(8, 2) TMPC_LDS(8, 4) TMPC_LDS(8, 8) TMPC_LDS(12, 2) TMPC_LDS(12, 4) TMPC_LDS(12, 8) TMPC_LDS(16, 2) TMPC_LDS(16, 4)
+// Compiled shapes (NVP, RD, KCP, RC).  Dense-only shapes cover the small problems (config 1);
+// the factored shapes cover the cartpole (terminal block of 420 rows, width 5).
+#define TMPC_SHAPES(X) \
+    X(8, 2, 0, 0) X(8, 4, 0, 0) X(12, 2, 0, 0) X(12, 4, 0, 0) X(16, 2, 0, 0) X(16, 4, 0, 0) \
+    X(12, 2, 6, 7)
+
+size_t lds_bytes(const KernelShape &s) {
+#define TMPC_LDS(A, B_, C, D) if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D) return kernel_lds_bytes<Shape<A, B_, C, D>>();
+    TMPC_SHAPES(TMPC_LDS)
 #undef TMPC_LDS
     return 0;
 }
 
-bool pick_config(int nv, int nc, int *nvp, int *rpl) {
-    static const int nvs[] = {8, 12, 16};
-    static const int rpls[] = {2, 4, 8};
-    for (int a : nvs) {
-        if (nv > a) continue;
-        for (int r : rpls) {
-            if (nc > r * WAVE) continue;
-            if (a == 16 && r == 8) continue;    // not instantiated (LDS/VGPR budget)
-            *nvp = a; *rpl = r;
-            return true;
-        }
+bool pick_config(int nv, int nd, int kc, int ncc, KernelShape *shape) {
+    static const int table[][4] = {
+#define TMPC_ROW(A, B_, C, D) {A, B_, C, D},
+        TMPC_SHAPES(TMPC_ROW)
+#undef TMPC_ROW
+    };
+    long best = -1;
+    for (const auto &t : table) {
+        if (nv > t[0] || nd > t[1] * WAVE || ncc > t[3] * WAVE) continue;
+        if ((kc > 0) != (t[2] > 0) || kc > t[2]) continue;
+        if (kc > 0 && nd > 0 && t[1] == 0) continue;
+        const long cost = static_cast<long>(t[0]) * t[0] * t[1] + static_cast<long>(t[2]) * t[2] * t[3] + t[0];
+        if (best < 0 || cost < best) { best = cost; shape->nvp = t[0]; shape->rd = t[1]; shape->kcp = t[2]; shape->rc = t[3]; }
     }
-    return false;
+    return best >= 0;
 }
 
-#define TMPC_CASE(NVV, RPLV)                                                                                         \
-    if (nvp == NVV && rpl == RPLV)                                                                                   \
-        return launch_one<NVV, RPLV>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream);
-
-hipError_t launch_solve(const DeviceQP &qp, int nvp, int rpl, int variant_id, int64_t B, const double *x_k,
+hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id, int64_t B, const double *x_k,
                         const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss,
                         double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
-    TMPC_CASE(8, 2) TMPC_CASE(8, 4) TMPC_CASE(8, 8)
-    TMPC_CASE(12, 2) TMPC_CASE(12, 4) TMPC_CASE(12, 8)
-    TMPC_CASE(16, 2) TMPC_CASE(16, 4)
+#define TMPC_CASE(A, B_, C, D)                                                                                       \
+    if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D)                                                         \
+        return launch_one<A, B_, C, D>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream);
+    TMPC_SHAPES(TMPC_CASE)
+#undef TMPC_CASE
     return hipErrorInvalidValue;
 }
 
