@@ -45,7 +45,7 @@ constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WCAP = 24;          // max rows in the refinement's working set
 constexpr int RED_ROWS = 16;      // entries per transposition round
-constexpr int RED_STRIDE = 65;    // 64 lanes + 1 pad: conflict-free transposed reads
+constexpr int RED_STRIDE = 68;    // 64 lanes + a pad after every 16: conflict-free transposed reads
 
 // Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of the first wave, written to
 // qp.dbg.  Never compiled into the shipped library; stamps fence the LDS queue and distort timing.
@@ -64,10 +64,12 @@ __device__ __forceinline__ void row_fence() {
 }
 
 __device__ __forceinline__ void wave_lds_fence() {
-    // all LDS traffic of this wave issued so far has completed, and the compiler may
-    // not move LDS accesses across this point (waves of a block run different QPs, so
-    // a block-wide barrier is not available here)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // Orders this wave's LDS traffic.  The hardware executes the DS instructions of one wave in
+    // issue order, so a read issued after a write (by any lane of the wave) observes it; what has to
+    // be stopped is the COMPILER moving LDS accesses across this point.  No s_waitcnt: the waits for
+    // returned data are inserted where the data is used.  (Waves of a block run different QPs, so a
+    // block-wide barrier is neither available nor needed here.)
+    asm volatile("" ::: "memory");
 }
 
 // 1/x to full double precision for normal, finite x: v_rcp_f64 + two Newton steps, without
@@ -116,22 +118,25 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 }
 
 // Sum each of acc[0..CNT) over the 64 lanes and leave the totals in out[0..CNT) (LDS).
-// Round: 16 entries are written as rows of a [16][65] LDS tile, lane l then adds a
-// 16-lane quarter (l>>4) of entry (l&15); the four quarters meet through two shuffles.
+// Round: 16 entries are written as rows of a [16][RED_STRIDE] LDS tile (lane l at column
+// l + l/16, i.e. one pad after every 16 lanes); lane l then adds the 16-lane quarter (l & 3) of
+// entry (l >> 2) -- conflict free for RED_STRIDE = 68 -- and the four quarters, which sit in one
+// quad, meet through two DPP quad permutes (no LDS round trip).
 template <int CNT>
 __device__ __forceinline__ void wave_reduce_to_lds(const double (&acc)[CNT], double *red, double *out, int lane) {
-    const int e = lane & 15, qd = lane >> 4;
+    const int e = lane >> 2, qd = lane & 3;
+    const int wcol = lane + (lane >> 4);
 #pragma unroll
     for (int c0 = 0; c0 < CNT; c0 += RED_ROWS) {
 #pragma unroll
         for (int k = 0; k < RED_ROWS; ++k)
-            if (c0 + k < CNT) red[k * RED_STRIDE + lane] = acc[c0 + k];
+            if (c0 + k < CNT) red[k * RED_STRIDE + wcol] = acc[c0 + k];
         wave_lds_fence();
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[e * RED_STRIDE + qd * 16 + j];
-        t += shfl_xor_d(t, 16);
-        t += shfl_xor_d(t, 32);
+        for (int j = 0; j < 16; ++j) t += red[e * RED_STRIDE + qd * 17 + j];
+        t += dpp_mov_d<0xB1>(t);
+        t += dpp_mov_d<0x4E>(t);
         if (qd == 0 && c0 + e < CNT) out[c0 + e] = t;
         wave_lds_fence();
     }
@@ -251,16 +256,17 @@ __device__ __forceinline__ bool slot_valid(int k, int lane, int nd, int ncc) {
 }
 
 // One sweep over the DENSE rows of this lane for columns [J0, J1) of the lower triangle of G'DG.
-// FIRST also forms r_p and 1/s; LAST also accumulates G'(d.r_p) and G'lam.
-template <class SH, int J0, int J1, bool FIRST, bool LAST>
+// The FIRST sweep loads whole rows anyway, so it also forms r_p and accumulates G'(d.r_p), G'lam,
+// the gap and |r_p|_inf.  Nothing per-row is kept besides (s, lam): r_p and 1/s are recomputed by
+// the later sweeps, which is cheaper than carrying them through the register file.
+template <class SH, int J0, int J1, bool FIRST>
 __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw, const double (&z)[SH::NV],
-                                              const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
-                                              double (&rs)[SH::RT], double &gap_l, double *red, double *sums, int lane, int nd) {
-    constexpr int NV = SH::NV, NDP = SH::NDP;
+                                              const double (&s)[SH::RT], const double (&lam)[SH::RT],
+                                              double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
+    constexpr int NV = SH::NV, NDP = SH::NDP, NT = SH::NT;
     constexpr int TRI = col_off<NV>(J1) - col_off<NV>(J0);
-    constexpr int CNT = TRI + (LAST ? 2 * NV : 0);
-    constexpr int I0 = (FIRST || LAST) ? 0 : J0;        // first column this sweep has to load
-    static_assert(!LAST || col_off<NV>(J1) == NV * (NV + 1) / 2, "the last block must end the triangle");
+    constexpr int CNT = TRI + (FIRST ? 2 * NV : 0);
+    constexpr int I0 = FIRST ? 0 : J0;        // first column this sweep has to load
     double acc[CNT];
 #pragma unroll
     for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
@@ -270,51 +276,61 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
         double g[NV];
 #pragma unroll
         for (int j = I0; j < NV; ++j) g[j] = Gt[j * NDP + r];
+        const double rsk = (r < nd) ? fast_rcp(s[k]) : 0.0;
+        const double d = lam[k] * rsk;
         if (FIRST) {
-            double gz = 0.0;
+            double gz0 = 0.0, gz1 = 0.0;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) gz += g[j] * z[j];
-            rp[k] = gz + s[k] - hw[k * WAVE + lane];
-            rs[k] = (r < nd) ? fast_rcp(s[k]) : 0.0;
+            for (int j = 0; j + 1 < NV; j += 2) { gz0 += g[j] * z[j]; gz1 += g[j + 1] * z[j + 1]; }
+            if (NV & 1) gz0 += g[NV - 1] * z[NV - 1];
+            const double rpk = (gz0 + gz1) + s[k] - hw[k * WAVE + lane];
             gap_l += s[k] * lam[k];
-        }
-        const double d = lam[k] * rs[k];
-#pragma unroll
-        for (int j = J0; j < J1; ++j) {
-            const double dg = d * g[j];
-#pragma unroll
-            for (int i = j; i < NV; ++i) acc[col_off<NV>(j) - col_off<NV>(J0) + i - j] += dg * g[i];
-        }
-        if (LAST) {
-            const double t = d * rp[k];
+            rpn_l = fmax(rpn_l, fabs(rpk));
+            const double t = d * rpk;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 acc[TRI + i] += g[i] * t;
                 acc[TRI + NV + i] += g[i] * lam[k];
             }
         }
+#pragma unroll
+        for (int j = J0; j < J1; ++j) {
+            const double dg = d * g[j];
+#pragma unroll
+            for (int i = j; i < NV; ++i) acc[col_off<NV>(j) - col_off<NV>(J0) + i - j] += dg * g[i];
+        }
         row_fence();
     }
-    // the triangle block lands at its packed position; the last block's two vectors follow the triangle
-    wave_reduce_to_lds<CNT>(acc, red, sums + col_off<NV>(J0), lane);
+    if (FIRST) {
+        // triangle block -> its packed position; the two vectors -> behind the triangle
+        double tri[TRI > 0 ? TRI : 1], vecs[2 * NV];
+#pragma unroll
+        for (int i = 0; i < TRI; ++i) tri[i] = acc[i];
+#pragma unroll
+        for (int i = 0; i < 2 * NV; ++i) vecs[i] = acc[TRI + i];
+        if constexpr (TRI > 0) wave_reduce_to_lds<TRI>(tri, red, sums + col_off<NV>(J0), lane);
+        wave_reduce_to_lds<2 * NV>(vecs, red, sums + NT, lane);
+    } else {
+        wave_reduce_to_lds<CNT>(acc, red, sums + col_off<NV>(J0), lane);
+    }
 }
 
 template <class SH, int BI>
 __device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double *hw, const double (&z)[SH::NV],
-                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
-                                                  double (&rs)[SH::RT], double &gap_l, double *red, double *sums, int lane, int nd) {
+                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT],
+                                                  double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
     using BL = Blocks<SH::NV>;
     if constexpr (BI < BL::n) {
-        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0, BI == BL::n - 1>(Gt, hw, z, s, lam, rp, rs, gap_l, red, sums, lane, nd);
-        sweep_a_dense_all<SH, BI + 1>(Gt, hw, z, s, lam, rp, rs, gap_l, red, sums, lane, nd);
+        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
+        sweep_a_dense_all<SH, BI + 1>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
     }
 }
 
 // The FACTORED rows: kc-wide left factor, so W = Hc' D Hc has only KT entries; one pass.
 template <class SH>
 __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double *hw, const double (&cz)[SH::KCA],
-                                                 const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
-                                                 double (&rs)[SH::RT], double &gap_l, double *red, double *csums, int lane, int ncc) {
+                                                 const double (&s)[SH::RT], const double (&lam)[SH::RT],
+                                                 double &gap_l, double &rpn_l, double *red, double *csums, int lane, int ncc) {
     constexpr int KC = SH::KC, KT = SH::KT, NCCP = SH::NCCP;
     double acc[KT + 2 * KC];
 #pragma unroll
@@ -326,11 +342,12 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
         double gz = 0.0;
 #pragma unroll
         for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * cz[a]; }
-        rp[k] = gz + s[k] - hw[k * WAVE + lane];
-        rs[k] = (rc < ncc) ? fast_rcp(s[k]) : 0.0;
+        const double rpk = gz + s[k] - hw[k * WAVE + lane];
+        const double rsk = (rc < ncc) ? fast_rcp(s[k]) : 0.0;
         gap_l += s[k] * lam[k];
-        const double d = lam[k] * rs[k];
-        const double t = d * rp[k];
+        rpn_l = fmax(rpn_l, fabs(rpk));
+        const double d = lam[k] * rsk;
+        const double t = d * rpk;
 #pragma unroll
         for (int a = 0; a < KC; ++a) {
             const double dg = d * hc[a];
@@ -341,6 +358,32 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
         }
     }
     wave_reduce_to_lds<KT + 2 * KC>(acc, red, csums, lane);
+}
+
+// (G_row . z, G_row . d1[, G_row . d2]) for the row in (slot K, this lane), sharing the row's loads
+template <class SH, int K, bool THREE>
+__device__ __forceinline__ void row_dots(const double *Gt, const double *Hct, const double (&z)[SH::NV], const double (&cz)[SH::KCA],
+                                         const double (&d1)[SH::NV], const double (&c1)[SH::KCA], const double (&d2)[SH::NV],
+                                         const double (&c2)[SH::KCA], int lane, double &o0, double &o1, double &o2) {
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    if constexpr (K < SH::RD) {
+        const int r = lane + K * WAVE;
+#pragma unroll
+        for (int j = 0; j < SH::NV; ++j) {
+            const double g = Gt[j * SH::NDP + r];
+            t0 += g * z[j]; t1 += g * d1[j];
+            if (THREE) t2 += g * d2[j];
+        }
+    } else {
+        const int rc = lane + (K - SH::RD) * WAVE;
+#pragma unroll
+        for (int a = 0; a < SH::KC; ++a) {
+            const double g = Hct[a * SH::NCCP + rc];
+            t0 += g * cz[a]; t1 += g * c1[a];
+            if (THREE) t2 += g * c2[a];
+        }
+    }
+    o0 = t0; o1 = t1; o2 = t2;
 }
 
 template <int NV, int RD, int KC, int RC>
@@ -484,14 +527,13 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             bool want_polish = false;
             for (; it < qp.max_iter; ++it) {
                 it_done = it;
-                // ---- sweeps A: residuals, 1/s, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam
-                double rp[RT], rs[RT];
-                double gap_l = 0.0;
-                if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, z, s, lam, rp, rs, gap_l, red, sums, lane, nd);
+                // ---- sweeps A: residuals, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam
+                double gap_l = 0.0, rpn_l = 0.0;
+                if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
                 if constexpr (KC > 0) {
                     double cz[KCA];
                     factor_coords<SH>(Psi, z, cz);
-                    sweep_a_factored<SH>(Hct, hw, cz, s, lam, rp, rs, gap_l, red, csums, lane, ncc);
+                    sweep_a_factored<SH>(Hct, hw, cz, s, lam, gap_l, rpn_l, red, csums, lane, ncc);
                     // fold the factored block into the dense totals: P = W Psi now, Psi' P when the rows are loaded
                     for (int idx = lane; idx < KC * NV; idx += WAVE) {
                         const int a = idx / NV, j = idx - a * NV;
@@ -514,10 +556,10 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                     if (lane < NV) { sums[NT + lane] = v1; sums[NT + NV + lane] = gl; }
                     wave_lds_fence();
                 }
-                double rpn = 0.0, lmax = 0.0;
+                double lmax = 0.0;
 #pragma unroll
-                for (int k = 0; k < RT; ++k) { rpn = fmax(rpn, fabs(rp[k])); lmax = fmax(lmax, lam[k]); }
-                rpn = wave_max(rpn);
+                for (int k = 0; k < RT; ++k) lmax = fmax(lmax, lam[k]);
+                const double rpn = wave_max(rpn_l);
                 lmax = wave_max(lmax);
                 const double gap = wave_sum(gap_l);
                 const double mu = gap / ncd;
@@ -590,21 +632,27 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
                 }
                 STAMP(3);
-                // ---- sweep B: affine step statistics and the corrector's G' products
-                double wprod[RT];
+                // ---- sweep B: affine step statistics and the corrector's G' products (r_p, 1/s recomputed per row)
+                double dza[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) dza[j] = dz[j];
                 double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
                 double v2 = 0.0, v3 = 0.0;          // lane i < NV: entries i of G'(dsa.dla/s) and G'(1/s)
                 {
-                    double cdz[KCA];
-                    if constexpr (KC > 0) factor_coords<SH>(Psi, dz, cdz);
-                    auto step_stats = [&](int k, bool valid, double gdz) {
-                        const double dsa = valid ? (-rp[k] - gdz) : 0.0;
-                        const double dla = valid ? (-lam[k] - lam[k] * rs[k] * dsa) : 0.0;
+                    double cz[KCA], cdz[KCA];
+                    if constexpr (KC > 0) { factor_coords<SH>(Psi, z, cz); factor_coords<SH>(Psi, dza, cdz); }
+                    // returns (dsa*dla/s, 1/s) of the row
+                    auto row_stats = [&](int k, bool valid, double gz, double gdz, double hk, double &c1, double &rsk) {
+                        rsk = valid ? fast_rcp(s[k]) : 0.0;
+                        const double rpk = gz + s[k] - hk;
+                        const double dsa = valid ? (-rpk - gdz) : 0.0;
+                        const double dla = valid ? (-lam[k] - lam[k] * rsk * dsa) : 0.0;
                         const double rl = valid ? fast_rcp(lam[k]) : 0.0;
-                        rho_aff = fmax(rho_aff, fmax(-dsa * rs[k], -dla * rl));
-                        wprod[k] = dsa * dla;
+                        rho_aff = fmax(rho_aff, fmax(-dsa * rsk, -dla * rl));
+                        const double w = dsa * dla;
                         sb1 += s[k] * dla + lam[k] * dsa;
-                        sb2 += wprod[k];
+                        sb2 += w;
+                        c1 = w * rsk;
                     };
                     if constexpr (RD > 0) {
                         double accb[2 * NV];
@@ -614,13 +662,13 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                         for (int k = 0; k < RD; ++k) {
                             const int r = lane + k * WAVE;
                             double g[NV];
-                            double gdz = 0.0;
+                            double gz = 0.0, gdz = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) { g[j] = Gt[j * NDP + r]; gdz += g[j] * dz[j]; }
-                            step_stats(k, r < nd, gdz);
-                            const double c1 = wprod[k] * rs[k];
+                            for (int j = 0; j < NV; ++j) { g[j] = Gt[j * NDP + r]; gz += g[j] * z[j]; gdz += g[j] * dza[j]; }
+                            double c1, rsk;
+                            row_stats(k, r < nd, gz, gdz, hw[k * WAVE + lane], c1, rsk);
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) { accb[j] += g[j] * c1; accb[NV + j] += g[j] * rs[k]; }
+                            for (int j = 0; j < NV; ++j) { accb[j] += g[j] * c1; accb[NV + j] += g[j] * rsk; }
                             row_fence();
                         }
                         wave_reduce_to_lds<2 * NV>(accb, red, sums + NT, lane);   // overwrites G'(d.rp), G'lam (consumed)
@@ -633,13 +681,13 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                         for (int k = RD; k < RT; ++k) {
                             const int rc = lane + (k - RD) * WAVE;
                             double hc[KC];
-                            double gdz = 0.0;
+                            double gz = 0.0, gdz = 0.0;
 #pragma unroll
-                            for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gdz += hc[a] * cdz[a]; }
-                            step_stats(k, rc < ncc, gdz);
-                            const double c1 = wprod[k] * rs[k];
+                            for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * cz[a]; gdz += hc[a] * cdz[a]; }
+                            double c1, rsk;
+                            row_stats(k, rc < ncc, gz, gdz, hw[k * WAVE + lane], c1, rsk);
 #pragma unroll
-                            for (int a = 0; a < KC; ++a) { accc[a] += hc[a] * c1; accc[KC + a] += hc[a] * rs[k]; }
+                            for (int a = 0; a < KC; ++a) { accc[a] += hc[a] * c1; accc[KC + a] += hc[a] * rsk; }
                         }
                         wave_reduce_to_lds<2 * KC>(accc, red, csums + KT, lane);
                     }
@@ -666,25 +714,31 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                     rows_backsub<NV>(mrow, bb, mdinv, dz);
                 }
                 STAMP(5);
-                // ---- sweep D: final direction, step length, update
-                double ds[RT];
+                // ---- sweep D: final direction, step length, update (row quantities recomputed once more)
+                double dsv[RT], dlv[RT];
                 double om = (1.0 - aaff) * (1.0 - aaff);
                 om = fmin(fmax(om, 1e-4), 1e-2);
                 const double tau = 1.0 - om;
                 double rho = 0.0;
                 {
-                    double cdz[KCA];
-                    if constexpr (KC > 0) factor_coords<SH>(Psi, dz, cdz);
+                    double cz[KCA], cdza[KCA], cdz[KCA];
+                    if constexpr (KC > 0) { factor_coords<SH>(Psi, z, cz); factor_coords<SH>(Psi, dza, cdza); factor_coords<SH>(Psi, dz, cdz); }
                     auto step_row = [&](auto kc_) {
                         constexpr int k = decltype(kc_)::value;
                         const bool valid = slot_valid<SH>(k, lane, nd, ncc);
-                        const double gdz = row_dot<SH, k>(Gt, Hct, dz, cdz, lane);
-                        ds[k] = valid ? (-rp[k] - gdz) : 0.0;
-                        const double rc = s[k] * lam[k] + wprod[k] - smu;
-                        const double dl = valid ? (-(rc + lam[k] * ds[k]) * rs[k]) : 0.0;
+                        double gz, gdza, gdz;
+                        row_dots<SH, k, true>(Gt, Hct, z, cz, dza, cdza, dz, cdz, lane, gz, gdza, gdz);
+                        const double rsk = valid ? fast_rcp(s[k]) : 0.0;
+                        const double rpk = gz + s[k] - hw[k * WAVE + lane];
+                        const double dsa = -rpk - gdza;
+                        const double dla = -lam[k] - lam[k] * rsk * dsa;
+                        const double dsk = valid ? (-rpk - gdz) : 0.0;
+                        const double rc = s[k] * lam[k] + dsa * dla - smu;
+                        const double dlk = valid ? (-(rc + lam[k] * dsk) * rsk) : 0.0;
                         const double rl = valid ? fast_rcp(lam[k]) : 0.0;
-                        rho = fmax(rho, fmax(-ds[k] * rs[k], -dl * rl));
-                        wprod[k] = dl;                        // the product is consumed; keep dl in its place
+                        rho = fmax(rho, fmax(-dsk * rsk, -dlk * rl));
+                        dsv[k] = dsk;
+                        dlv[k] = dlk;
                         if constexpr (k < RD) row_fence();
                     };
                     [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (step_row(std::integral_constant<int, Ks>{}), ...); }
@@ -693,7 +747,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
                 rho = wave_max(rho);
                 const double alpha = rho > tau ? tau / rho : 1.0;
 #pragma unroll
-                for (int k = 0; k < RT; ++k) { s[k] += alpha * ds[k]; lam[k] += alpha * wprod[k]; }
+                for (int k = 0; k < RT; ++k) { s[k] += alpha * dsv[k]; lam[k] += alpha * dlv[k]; }
 #pragma unroll
                 for (int j = 0; j < NV; ++j) z[j] += alpha * dz[j];
 #pragma unroll
