@@ -135,6 +135,14 @@ int tmpc_solve_batch_device(tmpc_handle *h, int64_t B,
                             double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                             int32_t *status, int32_t *iters);
 
+/*
+ * Experimental: batches of at least `min_batch` instances are iterated by the streaming kernel
+ * (16 lanes per QP, row state in an HBM/L2 workspace; csrc/tmpc_stream.hip) and only refined by
+ * the one-wave-per-QP kernel.  Off by default (min_batch <= 0 switches it off again); results are
+ * the same either way (tests/test_hip_parity.py::test_streaming_path_parity).
+ */
+int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch);
+
 /* Block until everything enqueued on the handle's stream has finished. */
 int tmpc_synchronize(tmpc_handle *h);
 

@@ -81,6 +81,8 @@ def lib():
         L.tmpc_solve_batch.restype = C.c_int
         L.tmpc_solve_batch_device.argtypes = sig
         L.tmpc_solve_batch_device.restype = C.c_int
+        L.tmpc_set_stream_min_batch.argtypes = [C.c_void_p, C.c_int64]
+        L.tmpc_set_stream_min_batch.restype = C.c_int
         L.tmpc_synchronize.argtypes = [C.c_void_p]
         L.tmpc_synchronize.restype = C.c_int
         L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -225,3 +227,9 @@ def kernel_ms_total(h: Handle, reset: bool = True):
     if lib().tmpc_kernel_ms_total(h.ptr, C.byref(ms), C.byref(cnt), int(reset)) != 0:
         raise RuntimeError(h.error())
     return float(ms.value), int(cnt.value)
+
+
+def set_stream_min_batch(h: Handle, min_batch: int):
+    """Experimental streaming path for batches >= min_batch (<= 0: off)."""
+    if lib().tmpc_set_stream_min_batch(h.ptr, int(min_batch)) != 0:
+        raise RuntimeError(h.error())

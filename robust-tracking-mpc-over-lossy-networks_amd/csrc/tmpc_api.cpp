@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <algorithm>
+#include <cstdint>
 #include <cstring>
 #include <new>
 #include <string>
@@ -20,6 +22,8 @@ struct Variant {
     tmpc::Condensed c;
     tmpc::DeviceQP d{};
     tmpc::KernelShape shape;
+    tmpc::StreamQP sq{};
+    bool stream_ok = false;
     std::vector<void *> dev;     // device allocations of this variant
 };
 
@@ -37,6 +41,12 @@ struct tmpc_handle {
     // event pairs of the launches since the last tmpc_kernel_ms_total(reset): per-launch device time
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t pool_used = 0;
+    // workspace of the streaming path: (s, lambda) per row, z, hand-over status / iteration count
+    int64_t ws_cap = 0;
+    int ws_ncp = 0;
+    double *ws_s = nullptr, *ws_lam = nullptr, *ws_z = nullptr;
+    int32_t *ws_stat = nullptr, *ws_it = nullptr;
+    int64_t stream_min_batch = INT64_MAX;   // streaming path is opt-in (tmpc_set_stream_min_batch); see DESIGN.md 5.3
     // staging buffers for the host-pointer entry point
     int64_t cap = 0;
     double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
@@ -124,6 +134,23 @@ int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload(h, v, c.Mth.a.data(), c.Mth.a.size(), &d.Mth))) return rc;
     if ((rc = upload(h, v, p.A, static_cast<size_t>(nx) * nx, &d.A))) return rc;
     if ((rc = upload(h, v, p.B, static_cast<size_t>(nx) * c.nu, &d.B))) return rc;
+    // streaming path: every row dense, row order of Condensed::Gs
+    {
+        const int ncp = (c.nc + 63) / 64 * 64;
+        v.stream_ok = tmpc::stream_supported(NVP, ncp, nx);
+        if (v.stream_ok) {
+            std::vector<double> Gd(static_cast<size_t>(NVP) * ncp, 0.0), g0d(ncp, 1.0), Esd(static_cast<size_t>(ncp) * nx, 0.0);
+            for (int r = 0; r < c.nc; ++r) {
+                for (int j = 0; j < c.nv; ++j) Gd[static_cast<size_t>(j) * ncp + r] = c.Gs(r, j);
+                g0d[r] = c.g0s[r];
+                for (int j = 0; j < nx; ++j) Esd[static_cast<size_t>(r) * nx + j] = c.Es(r, j);
+            }
+            v.sq.ncp = ncp;
+            if ((rc = upload(h, v, Gd.data(), Gd.size(), &v.sq.Gd))) return rc;
+            if ((rc = upload(h, v, g0d.data(), g0d.size(), &v.sq.g0d))) return rc;
+            if ((rc = upload(h, v, Esd.data(), Esd.size(), &v.sq.Esd))) return rc;
+        }
+    }
     d.dbg = nullptr;
 #ifdef TMPC_STAMPS
     {
@@ -181,7 +208,30 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     for (int k = 0; k < h->nvariants; ++k) {
         if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
         Variant &v = h->v[k];
-        HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
+        tmpc::WarmStart warm{};
+        if (v.stream_ok && B >= h->stream_min_batch) {
+            // large batch: 16-lane-per-QP streaming iteration first, refinement by the wave-per-QP kernel
+            if (B > h->ws_cap || v.sq.ncp > h->ws_ncp) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                void *old_p[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it};
+                for (void *q2 : old_p) if (q2) (void)hipFree(q2);
+                int ncp_max = 0;
+                for (int kk = 0; kk < h->nvariants; ++kk) ncp_max = std::max(ncp_max, h->v[kk].sq.ncp);
+                const size_t b2 = static_cast<size_t>(B);
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_s), b2 * ncp_max * sizeof(double)));
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_lam), b2 * ncp_max * sizeof(double)));
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_z), b2 * 32 * sizeof(double)));
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_stat), b2 * sizeof(int32_t)));
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_it), b2 * sizeof(int32_t)));
+                h->ws_cap = B;
+                h->ws_ncp = ncp_max;
+            }
+            HIP_TRY(h, tmpc::launch_stream(v.d, v.sq, v.shape.nvp, k, B, x_k, ref, variant, h->ws_s, h->ws_lam, h->ws_z,
+                                           h->ws_stat, h->ws_it, h->stream));
+            warm.s = h->ws_s; warm.lam = h->ws_lam; warm.z = h->ws_z; warm.stat = h->ws_stat; warm.it = h->ws_it;
+            warm.ncp = v.sq.ncp;
+        }
+        HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, warm, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
                                       iters, h->n_cu, h->stream));
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
@@ -259,6 +309,10 @@ void tmpc_destroy(tmpc_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
+    {
+        void *wsp[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it};
+        for (void *q2 : wsp) if (q2) (void)hipFree(q2);
+    }
     for (int k = 0; k < 2; ++k)
         for (void *p : h->v[k].dev) (void)hipFree(p);
     for (auto &pr : h->pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -302,6 +356,12 @@ int tmpc_solve_batch(tmpc_handle *h, int64_t B, const double *x_k, const double 
     HIP_TRY(h, hipMemcpyAsync(status, h->d_st, b * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipMemcpyAsync(iters, h->d_it, b * sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
     HIP_TRY(h, hipStreamSynchronize(h->stream));
+    return TMPC_OK;
+}
+
+int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch) {
+    if (!h) return TMPC_E_INVALID;
+    h->stream_min_batch = min_batch > 0 ? min_batch : INT64_MAX;
     return TMPC_OK;
 }
 

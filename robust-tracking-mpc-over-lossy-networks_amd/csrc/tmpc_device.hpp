@@ -38,6 +38,21 @@ struct DeviceQP {
     long long *dbg;       // diagnostic builds only (TMPC_STAMPS); nullptr otherwise
 };
 
+// Streaming path (tmpc_stream.hip): all rows dense, in the row order of Condensed::Gs
+struct StreamQP {
+    int ncp;              // row stride of the workspace and of Gd (multiple of 64, >= nc)
+    const double *Gd;     // [NVP][ncp] scaled G, transposed, zero padded
+    const double *g0d;    // [ncp]
+    const double *Esd;    // [ncp][nx]
+};
+
+// State handed from the streaming kernel to solve_kernel (warm mode); z == nullptr: cold start
+struct WarmStart {
+    const double *s, *lam, *z;
+    const int32_t *stat, *it;
+    int ncp;
+};
+
 struct KernelShape {
     int nvp = 0, rd = 0, kcp = 0, rc = 0;
 };
@@ -47,8 +62,14 @@ struct KernelShape {
 bool pick_config(int nv, int nd, int kc, int ncc, KernelShape *shape);
 size_t lds_bytes(const KernelShape &shape);
 
-hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, int variant_id, int64_t B, const double *x_k,
-                        const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss,
-                        double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream);
+hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, const WarmStart &warm, int variant_id, int64_t B,
+                        const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream);
+
+size_t stream_lds_bytes(int nvp, int ncp, int nx);
+bool stream_supported(int nvp, int ncp, int nx);
+hipError_t launch_stream(const DeviceQP &qp, const StreamQP &sq, int nvp, int variant_id, int64_t B, const double *x_k,
+                         const double *ref, const uint8_t *variant, double *ws_s, double *ws_lam, double *ws_z,
+                         int32_t *ws_stat, int32_t *ws_iters, hipStream_t stream);
 
 }  // namespace tmpc

@@ -388,7 +388,7 @@ __device__ __forceinline__ void row_dots(const double *Gt, const double *Hct, co
 
 template <int NV, int RD, int KC, int RC>
 __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
-    const DeviceQP qp, const int variant_id, const int64_t B,
+    const DeviceQP qp, const WarmStart warm, const int variant_id, const int64_t B,
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
@@ -501,9 +501,14 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
         smin = wave_min(smin);
         STAMP(0);
 
+        // warm mode: the streaming kernel has already iterated this instance (tmpc_stream.hip)
+        const int st1 = warm.z ? warm.stat[b] : -1;
         if (infeasible_par) {
             st = TMPC_STATUS_INFEASIBLE;
-        } else if (smin >= 0.0) {
+        } else if (st1 == TMPC_STATUS_INFEASIBLE || st1 == TMPC_STATUS_NUMERICAL) {
+            st = st1;
+            it_done = warm.it[b];
+        } else if (st1 == 4 || (st1 < 0 && smin >= 0.0)) {
             st = TMPC_STATUS_OPTIMAL;
         } else {
             // -------------------------------------------------------- interior point
@@ -521,10 +526,34 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             const double ncd = static_cast<double>(nc);
             int it = 0;
             double rdn_last = 0.0;
+            bool skip_ipm = false;
+            if (st1 == 0 || st1 == 1) {
+                // pick up (z, s, lambda) where the streaming kernel left them
+#pragma unroll
+                for (int j = 0; j < NV; ++j) z[j] = warm.z[b * NV + j];
+#pragma unroll
+                for (int k = 0; k < RT; ++k) {
+                    const int gid = k < RD ? lane + k * WAVE : nd + lane + (k - RD) * WAVE;
+                    const bool valid = slot_valid<SH>(k, lane, nd, ncc);
+                    s[k] = valid ? warm.s[b * warm.ncp + gid] : 1.0;
+                    lam[k] = valid ? warm.lam[b * warm.ncp + gid] : 0.0;
+                }
+#pragma unroll
+                for (int j = 0; j < NV; ++j) if (lane == j) zv[j] = z[j];
+                wave_lds_fence();
+                it = warm.it[b];
+                it_done = it;
+                skip_ipm = true;
+                rdn_last = INFINITY;
+            }
             // interior point until the active set can be read off, then the refinement; the pair is
             // repeated (with a tighter hand-over tolerance) only if the refinement cannot certify its set
             for (;;) {
             bool want_polish = false;
+            if (skip_ipm) {
+                want_polish = (st1 == 0);       // hand-over point reached: refine; iteration cap: fall through
+                skip_ipm = false;
+            } else
             for (; it < qp.max_iter; ++it) {
                 it_done = it;
                 // ---- sweeps A: residuals, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam
@@ -1031,7 +1060,7 @@ constexpr size_t kernel_lds_bytes() {
 }
 
 template <int NV, int RD, int KC, int RC>
-hipError_t launch_one(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
+hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
     constexpr size_t lds = kernel_lds_bytes<Shape<NV, RD, KC, RC>>();
@@ -1051,7 +1080,7 @@ hipError_t launch_one(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((solve_kernel<NV, RD, KC, RC>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WAVES_PER_BLOCK), lds, stream,
-                       qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
+                       qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
     return hipGetLastError();
 }
 
@@ -1087,12 +1116,12 @@ bool pick_config(int nv, int nd, int kc, int ncc, KernelShape *shape) {
     return best >= 0;
 }
 
-hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id, int64_t B, const double *x_k,
-                        const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss,
-                        double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
+hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, const WarmStart &warm, int variant_id, int64_t B,
+                        const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
 #define TMPC_CASE(A, B_, C, D)                                                                                       \
     if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D)                                                         \
-        return launch_one<A, B_, C, D>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream);
+        return launch_one<A, B_, C, D>(qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream);
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE
     return hipErrorInvalidValue;

@@ -176,6 +176,26 @@ def test_device_pointer_entry_with_torch(cartpole, hip_lib):
     assert np.array_equal(st.cpu().numpy(), host["status"])
 
 
+def test_streaming_path_parity(cartpole, hip_lib):
+    """The opt-in streaming kernel (16 lanes per QP) + warm-started refinement gives the same
+    minimisers as the default one-wave-per-QP path and as the fixture."""
+    mpc, _, _ = cartpole
+    gold = np.load(os.path.join(common.GOLDEN, "cartpole_N10_oracle.npz"))
+    X = np.r_[S[:, :4], [[0.0, 0.0, 0.2, 0.0], [0.5, 0.0, 0.0, 0.0]]]      # + infeasible, + unconstrained
+    R = np.r_[S[:, 4:], [[0.5, 0, 0, 0.0], [0.5, 0, 0, 0.0]]]
+    base = mpc._solve(X, R)
+    hip_lib.set_stream_min_batch(mpc._handle, 1)
+    try:
+        out = mpc._solve(X, R)
+    finally:
+        hip_lib.set_stream_min_batch(mpc._handle, 0)
+    assert np.array_equal(out["status"], base["status"]) and list(out["status"][-2:]) == [2, 0]
+    np.testing.assert_allclose(out["u_nom"][:600], gold["u_nom"], atol=ATOL_U, rtol=0)
+    np.testing.assert_allclose(out["xu_ss"][:600], gold["xu_ss"], atol=ATOL_SS, rtol=0)
+    np.testing.assert_allclose(out["u_nom"][-1], base["u_nom"][-1], atol=1e-12)
+    assert np.all(np.isnan(out["u_nom"][-2]))
+
+
 @pytest.mark.parametrize("N", [5, 10])
 def test_config1_double_integrator_closed_loop(hip_lib, oracle_lib, N):
     """BASELINE config 1: Example_of_Tube_Tracking_MPC.py (free initial state, Rakovic sets,
