@@ -151,7 +151,7 @@ template <int NV> struct Blocks;
 template <> struct Blocks<8>  { static constexpr int n = 2; static constexpr int b[3] = {0, 3, 8}; };
 template <> struct Blocks<12> { static constexpr int n = 3; static constexpr int b[4] = {0, 3, 7, 12}; };
 template <> struct Blocks<16> { static constexpr int n = 5; static constexpr int b[6] = {0, 2, 4, 7, 11, 16}; };
-template <> struct Blocks<24> { static constexpr int n = 9; static constexpr int b[10] = {0, 2, 4, 6, 8, 10, 13, 16, 19, 24}; };
+template <> struct Blocks<24> { static constexpr int n = 10; static constexpr int b[11] = {0, 1, 3, 5, 7, 9, 11, 14, 17, 20, 24}; };
 
 // ---- nv x nv solve, rows distributed over lanes.
 // Lane i (< NV) holds row i of the symmetric positive definite M in registers.  Gaussian
@@ -386,8 +386,8 @@ __device__ __forceinline__ void row_dots(const double *Gt, const double *Hct, co
     o0 = t0; o1 = t1; o2 = t2;
 }
 
-template <int NV, int RD, int KC, int RC>
-__global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
+template <int NV, int RD, int KC, int RC, bool WARM, int WPB>
+__global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const DeviceQP qp, const WarmStart warm, const int variant_id, const int64_t B,
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
@@ -428,8 +428,8 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
     double *tv = vec + 3 * NV + 32;   // [NV] scratch
     double *uv = vec + 4 * NV + 32;   // [NV] scratch
 
-    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * WAVES_PER_BLOCK + wave;
-    const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * WAVES_PER_BLOCK;
+    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * WPB + wave;
+    const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * WPB;
 
     for (int64_t b = wave_global; b < B; b += wave_stride) {
         if (variant != nullptr && variant[b] != variant_id) continue;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
         STAMP(0);
 
         // warm mode: the streaming kernel has already iterated this instance (tmpc_stream.hip)
-        const int st1 = warm.z ? warm.stat[b] : -1;
+        const int st1 = WARM ? warm.stat[b] : -1;
         if (infeasible_par) {
             st = TMPC_STATUS_INFEASIBLE;
         } else if (st1 == TMPC_STATUS_INFEASIBLE || st1 == TMPC_STATUS_NUMERICAL) {
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             int it = 0;
             double rdn_last = 0.0;
             bool skip_ipm = false;
-            if (st1 == 0 || st1 == 1) {
+            if (WARM && (st1 == 0 || st1 == 1)) {
                 // pick up (z, s, lambda) where the streaming kernel left them
 #pragma unroll
                 for (int j = 0; j < NV; ++j) z[j] = warm.z[b * NV + j];
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
             // repeated (with a tighter hand-over tolerance) only if the refinement cannot certify its set
             for (;;) {
             bool want_polish = false;
-            if (skip_ipm) {
+            if (WARM && skip_ipm) {
                 want_polish = (st1 == 0);       // hand-over point reached: refine; iteration cap: fall through
                 skip_ipm = false;
             } else
@@ -1054,32 +1054,39 @@ __global__ __launch_bounds__(WAVE *WAVES_PER_BLOCK, 1) void solve_kernel(
 }
 
 template <class SH>
-constexpr size_t kernel_lds_bytes() {
+constexpr size_t kernel_lds_bytes(int wpb) {
     return sizeof(double) * (static_cast<size_t>(SH::NV) * SH::NDP + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
-                             WAVES_PER_BLOCK * WaveLds<SH>::TOTAL);
+                             static_cast<size_t>(wpb) * WaveLds<SH>::TOTAL);
+}
+// four waves per workgroup (one per SIMD) unless the per-wave workspace does not leave room for that
+template <class SH>
+constexpr int waves_per_block() {
+    return kernel_lds_bytes<SH>(4) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3) <= 160 * 1024 ? 3 : 2);
 }
 
-template <int NV, int RD, int KC, int RC>
+template <int NV, int RD, int KC, int RC, bool WARM>
 hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
-    constexpr size_t lds = kernel_lds_bytes<Shape<NV, RD, KC, RC>>();
+    using SH = Shape<NV, RD, KC, RC>;
+    constexpr int WPB = waves_per_block<SH>();
+    constexpr size_t lds = kernel_lds_bytes<SH>(WPB);
     static_assert(lds <= 160 * 1024, "shape does not fit the 160 KiB LDS of a CU");
     // > 64 KiB of dynamic LDS needs the opt-in once per device and instantiation
     static bool attr_set[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, RD, KC, RC>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, RD, KC, RC, WARM, WPB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
-    int64_t blocks = (B + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    int64_t blocks = (B + WPB - 1) / WPB;
     const int64_t cap = static_cast<int64_t>(n_cu) * 4;     // a few workgroups per CU, grid-stride over the batch
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((solve_kernel<NV, RD, KC, RC>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WAVES_PER_BLOCK), lds, stream,
+    hipLaunchKernelGGL((solve_kernel<NV, RD, KC, RC, WARM, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
                        qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
     return hipGetLastError();
 }
@@ -1087,13 +1094,13 @@ hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id,
 }  // namespace
 
 // Compiled shapes (NVP, RD, KCP, RC).  Dense-only shapes cover the small problems (config 1);
-// the factored shapes cover the cartpole (terminal block of 420 rows, width 5).
+// the factored shapes cover the cartpole (terminal block of 420 rows, width 5) at N = 10 and N = 20.
 #define TMPC_SHAPES(X) \
     X(8, 2, 0, 0) X(8, 4, 0, 0) X(12, 2, 0, 0) X(12, 4, 0, 0) X(16, 2, 0, 0) X(16, 4, 0, 0) \
-    X(12, 2, 6, 7)
+    X(12, 2, 6, 7) X(24, 3, 6, 7)
 
 size_t lds_bytes(const KernelShape &s) {
-#define TMPC_LDS(A, B_, C, D) if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D) return kernel_lds_bytes<Shape<A, B_, C, D>>();
+#define TMPC_LDS(A, B_, C, D) if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D) return kernel_lds_bytes<Shape<A, B_, C, D>>(waves_per_block<Shape<A, B_, C, D>>());
     TMPC_SHAPES(TMPC_LDS)
 #undef TMPC_LDS
     return 0;
@@ -1121,7 +1128,8 @@ hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, const WarmStar
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
 #define TMPC_CASE(A, B_, C, D)                                                                                       \
     if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D)                                                         \
-        return launch_one<A, B_, C, D>(qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream);
+        return warm.z ? launch_one<A, B_, C, D, true>(qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream) \
+                      : launch_one<A, B_, C, D, false>(qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, n_cu, stream);
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE
     return hipErrorInvalidValue;

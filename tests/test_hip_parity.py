@@ -176,6 +176,20 @@ def test_device_pointer_entry_with_torch(cartpole, hip_lib):
     assert np.array_equal(st.cpu().numpy(), host["status"])
 
 
+def test_reference_horizon_N20(hip_lib, oracle_lib):
+    """The horizon the reference's cartpole scripts use (results_linear_system.py:64, N = 20):
+    nv = 21, 184 dense rows + the 420-row terminal block in factored form."""
+    S20 = common.harvest_states("cartpole", 20, True, [[0.5, 0.0], [3.0, 0.0], [-2.0, 1.0]], steps=40)
+    mpc, _ = common.make_mpc("cartpole", 20, True, create=True)
+    assert hip_lib.get_dims(mpc._handle)[0] == 21
+    ref = Oracle(mpc._problem_dict()).solve(S20[:, :4], S20[:, 4:])
+    out = mpc._solve(S20[:, :4], S20[:, 4:])
+    assert np.array_equal(out["status"], ref["status"]) and np.all(ref["status"] == 0)
+    np.testing.assert_allclose(out["u_nom"], ref["u_nom"], atol=ATOL_U, rtol=0)
+    np.testing.assert_allclose(out["xu_ss"], ref["xu_ss"], atol=ATOL_SS, rtol=0)
+    np.testing.assert_allclose(out["x_nom"], ref["x_nom"], atol=1e-8, rtol=0)
+
+
 def test_streaming_path_parity(cartpole, hip_lib):
     """The opt-in streaming kernel (16 lanes per QP) + warm-started refinement gives the same
     minimisers as the default one-wave-per-QP path and as the fixture."""
