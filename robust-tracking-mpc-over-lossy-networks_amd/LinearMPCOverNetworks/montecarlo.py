@@ -47,3 +47,76 @@ def gather_statistics(local, n_total: int, rank: int, world: int, group=None):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad, group=group)
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+# --------------------------------------------------------------------------- closed loop
+def draw_realisations(n_traj: int, T: int, w_bound, seed: int = 20240301, first: int = 0):
+    """Per-trajectory random streams (uniforms for theta, gamma and the disturbance), so that a
+    trajectory's realisation does not depend on how the sweep is sharded.  Trajectory g uses
+    SeedSequence(seed, spawn_key=(g,)).  (The reference draws from three shared generators in loop
+    order, results_linear_system.py:21-23,218-233; that order cannot be kept under sharding.)"""
+    w_bound = np.asarray(w_bound, dtype=np.float64)
+    th = np.empty((n_traj, T))
+    ga = np.empty((n_traj, T))
+    w = np.empty((n_traj, T, w_bound.size))
+    for i in range(n_traj):
+        rng = np.random.default_rng(np.random.SeedSequence(seed, spawn_key=(first + i,)))
+        th[i] = rng.uniform(size=T)
+        ga[i] = rng.uniform(size=T)
+        w[i] = rng.uniform(-1.0, 1.0, size=(T, w_bound.size)) * w_bound
+    return th, ga, w
+
+
+def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None):
+    """Closed loop of the remote tube-based MPC over a lossy network for a batch of trajectories:
+    the body of the reference's Monte-Carlo loop (results_linear_system.py:209-259, 291) with the
+    per-trajectory objects replaced by the batched state machines and the QP solves of one time
+    step done by ONE call of `packets_fn(x_hat (B,nx), ref_t (B,nx)) -> (U_t (B,nu,N+1), x_nom0,
+    status (B,))` -- normally `TubeTrackingMPC.determine_packets`, i.e. one kernel launch.
+
+    p_loss (B,), ref (T,) position reference, th_u/ga_u (B,T) uniforms, w (B,T,nx) disturbances.
+    Returns a dict of per-trajectory statistics."""
+    from .Estimator import BatchedEstimator
+    from .SmartActuator import BatchedConsistentActuator
+    A = np.asarray(A, dtype=np.float64)
+    Bm = np.asarray(B, dtype=np.float64)
+    nb, T = th_u.shape
+    nx = A.shape[0]
+    p_loss = np.asarray(p_loss, dtype=np.float64).reshape(nb)
+    x = np.zeros((nb, nx)) if x0 is None else np.array(x0, dtype=np.float64).reshape(nb, nx)
+    est = BatchedEstimator(A, Bm, K, x, N)
+    act = BatchedConsistentActuator(A, Bm, K, K_plant, x)
+    err2 = np.zeros(nb)
+    tube_viol = np.zeros(nb, dtype=np.int32)
+    not_optimal = np.zeros(nb, dtype=np.int32)
+    consistent_err = 0.0
+    U_prev = None
+    for t in range(T):
+        theta = np.where(th_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :211-226, strict <
+        gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)
+        r_t = np.zeros((nb, nx))
+        r_t[:, 0] = ref[t]
+        q_t = est.get_qt()
+        U_t, _, status = packets_fn(est.get_estimate(), r_t)                                       # :240
+        bad = status >= 2
+        not_optimal += (status != 0)
+        if bad.any():
+            # the reference's tube branch has no handling for a failed solve (it would raise); here the
+            # packet of such a trajectory is treated as lost and its previous sequence stays in use
+            U_t = np.where(bad[:, None, None], U_prev if U_prev is not None else 0.0, U_t)
+            theta = np.where(bad, 0, theta)
+        U_prev = U_t
+        est.store(U_t)                                                                             # :242
+        x_nom_t = act.x_nom.copy()
+        u, pkt = act.process(U_t, q_t, x, theta)                                                   # :244
+        err2 += (x[:, 0] - ref[t]) ** 2 + np.sum(x[:, 1:] ** 2, axis=1)                            # :291 (x_t, t = 0..T-1)
+        tube_viol += ~np.asarray(Z.contains((x - x_nom_t).T)).reshape(nb)                          # :258
+        x = x @ A.T + u @ Bm.T + w[:, t]                                                           # :248
+        est.update(pkt, gamma)                                                                     # :254
+        # Proposition 1 of the paper: whenever the actuator is consistent and the plant packet arrives,
+        # the estimate equals the nominal plant state
+        ok = (act.Theta == 1) & (gamma == 1)
+        if ok.any():
+            consistent_err = max(consistent_err, float(np.max(np.abs(est.x_hat[ok] - act.x_nom[ok]))))
+    return dict(tracking_error=np.sqrt(err2) / T, tube_violations=tube_viol, not_optimal=not_optimal,
+                consistent_estimate_error=consistent_err, x_final=x)

@@ -1,0 +1,57 @@
+"""Closed loop over a lossy network (results_linear_system.py:209-291) driven by the batched state
+machines.  The CPU test uses the oracle as the solver (tests may); the GPU test uses the product
+path and compares trajectories with the oracle-driven loop."""
+import numpy as np
+import pytest
+
+import common
+from LinearMPCOverNetworks import montecarlo
+from oracle.oracle import Oracle
+
+
+def _oracle_packets(mpc, orc):
+    def fn(x_hat, r):
+        sol = orc.solve(x_hat, r)
+        u_ss = sol["u_ss"] + sol["x_ss"] @ mpc._K.T                        # TubeTrackingMPC.py:217
+        U = np.concatenate([sol["u_nom"], u_ss[:, None, :]], axis=1).transpose(0, 2, 1)
+        return np.ascontiguousarray(U), sol["x_nom0"], sol["status"]
+    return fn
+
+
+def _setup(nb, T, seed=7):
+    mpc, w = common.make_mpc("cartpole", 10, True)
+    p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=seed)
+    ref = 0.5 * np.ones(T)
+    return mpc, w, p_loss, th, ga, dist, ref
+
+
+def test_closed_loop_invariants_cpu(oracle_lib):
+    nb, T = 8, 40
+    mpc, w, p_loss, th, ga, dist, ref = _setup(nb, T)
+    orc = Oracle(mpc._problem_dict())
+    K = mpc.get_steady_state_controller_gain()
+    out = montecarlo.run_remote_tube_mpc(_oracle_packets(mpc, orc), w["A"], w["B"], K, mpc.get_ancillary_controller_gain(),
+                                         10, mpc._Z, p_loss, ref, th, ga, dist)
+    assert np.all(out["not_optimal"] == 0)
+    assert np.all(out["tube_violations"] == 0)               # x_t - x_nom_t in Z: the paper's tube guarantee (:258)
+    assert out["consistent_estimate_error"] < 1e-9           # Proposition 1
+    assert np.all(np.isfinite(out["tracking_error"])) and out["tracking_error"].max() < 0.2
+    # realisations do not depend on the sharding: trajectory 5 drawn alone equals row 5 of the batch
+    th1, ga1, d1 = montecarlo.draw_realisations(1, T, w["w_bound"], seed=7, first=5)
+    assert np.array_equal(th1[0], th[5]) and np.array_equal(d1[0], dist[5])
+
+
+@pytest.mark.gpu
+def test_closed_loop_gpu_matches_oracle_loop(hip_lib, oracle_lib):
+    nb, T = 64, 60
+    mpc, w, p_loss, th, ga, dist, ref = _setup(nb, T, seed=11)
+    mpc_gpu, _ = common.make_mpc("cartpole", 10, True, create=True)
+    orc = Oracle(mpc._problem_dict())
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    a = montecarlo.run_remote_tube_mpc(mpc_gpu.determine_packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist)
+    b = montecarlo.run_remote_tube_mpc(_oracle_packets(mpc, orc), w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist)
+    assert np.all(a["not_optimal"] == 0) and np.all(a["tube_violations"] == 0)
+    np.testing.assert_allclose(a["x_final"], b["x_final"], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(a["tracking_error"], b["tracking_error"], atol=1e-9, rtol=0)
+    assert a["consistent_estimate_error"] < 1e-9
