@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define TMPC_ABI_VERSION 1
+#define TMPC_ABI_VERSION 2
 
 /* error codes (function return values) */
 #define TMPC_OK            0
@@ -57,6 +57,9 @@ extern "C" {
  *             {HT [x_N; x_bar; u_bar] <= hT}  rT rows, terminal set Xf in R^(2nx+nu) (TubeTrackingMPC.py:114,149)
  *             {HZ e <= hZ}   rZ rows, mRPI set Z; used iff fixed_x0 == 0  (TubeTrackingMPC.py:130-132)
  *             {HZW e <= hZW} rZW rows, Z (-) W; used iff extended != 0    (TubeTrackingMPC.py:266-278)
+ *             {HTP [x_bar; u_bar] <= hTP} rTP rows (optional, extended only): the terminal row block of the
+ *                            packet-received problem (TubeTrackingMPC.py:293) with its free auxiliaries
+ *                            eliminated, i.e. proj(Xf) on the steady-state subspace -- see below
  *
  * fixed_x0 : 1 -> x_0 == x_k (TubeTrackingMPC.py:127); 0 -> HZ (x_k - x_0) <= hZ (TubeTrackingMPC.py:132).
  * extended : 1 -> a second QP ("variant 1") is prepared for instances whose
@@ -65,6 +68,13 @@ extern "C" {
  *            variant 1 the terminal inequality is written on x_mpc[:,N] and u_bar of the
  *            *base* problem, i.e. on free auxiliary variables; 0 uses the variant's own
  *            x_N and u_bar instead.
+ *            The auxiliaries are not priced, so line :293 only says x_bar in proj_xbar(Xf).  When the
+ *            caller supplies that projection (HTP, hTP; LinearMPCOverNetworks/utils_polytope.py:
+ *            eliminate_terminal_auxiliaries computes it exactly at set-up time) the auxiliaries are
+ *            dropped and the QP stays strictly convex: the minimiser in (x, u, x_bar, u_bar) is the
+ *            same.  Without it (rTP == 0) the auxiliaries are kept with a vanishing weight
+ *            2e-6 min(diag R) |aux|^2; that problem is badly conditioned and its solution is only
+ *            reliable to ~1e-5.
  * tol      : relative primal-residual / duality-gap level at which the interior-point
  *            phase hands over to the exact active-set refinement; <= 0 selects the
  *            default 1e-7 (tightened by 1e-2 and retried whenever the refinement
@@ -79,6 +89,8 @@ typedef struct tmpc_problem {
     double  tol;
     const double *A, *B, *Q, *R, *P, *T, *K, *K_anc;
     const double *Hx, *hx, *Hu, *hu, *HT, *hT, *HZ, *hZ, *HZW, *hZW;
+    const double *HTP, *hTP;    /* rTP x (nx+nu), rTP; may be NULL */
+    int32_t rTP;
 } tmpc_problem;
 
 typedef struct tmpc_handle tmpc_handle;
@@ -142,6 +154,20 @@ int tmpc_solve_batch_device(tmpc_handle *h, int64_t B,
  * the same either way (tests/test_hip_parity.py::test_streaming_path_parity).
  */
 int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch);
+
+/*
+ * Which kernel solves a variant.  TMPC_PATH_AUTO (default): the one-wave-per-QP kernel
+ * (csrc/tmpc_kernels.hip) when one of its compiled shapes covers the condensed problem, otherwise
+ * the workgroup-per-QP kernel (csrc/tmpc_block.hip: nv <= 128, any number of rows, G'DG on the
+ * FP64 matrix cores).  TMPC_PATH_WAVE / TMPC_PATH_BLOCK force one of them (TMPC_E_UNSUPPORTED if
+ * it cannot take the problem).  Results agree to the refinement's accuracy either way
+ * (tests/test_hip_parity.py).  tmpc_get_kernel_path reports the path a variant currently takes.
+ */
+#define TMPC_PATH_AUTO  0
+#define TMPC_PATH_WAVE  1
+#define TMPC_PATH_BLOCK 2
+int tmpc_set_kernel_path(tmpc_handle *h, int path);
+int tmpc_get_kernel_path(const tmpc_handle *h, int variant);
 
 /* Block until everything enqueued on the handle's stream has finished. */
 int tmpc_synchronize(tmpc_handle *h);

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 _PTR_FIELDS = ["A", "B", "Q", "R", "P", "T", "K", "K_anc",
-               "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW"]
+               "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW", "HTP", "hTP"]
 
 
 class Problem(C.Structure):
@@ -24,7 +24,7 @@ class Problem(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("nx", "nu", "N", "rx", "ru", "rT", "rZ", "rZW",
                                           "fixed_x0", "extended", "literal_terminal_row", "max_iter")]
                 + [("tol", C.c_double)]
-                + [(n, C.POINTER(C.c_double)) for n in _PTR_FIELDS])
+                + [(n, C.POINTER(C.c_double)) for n in _PTR_FIELDS] + [("rTP", C.c_int32)])
 
 
 def pack_problem(d: dict):
@@ -63,7 +63,8 @@ def pack_problem(d: dict):
     p.rx, p.ru = rows("Hx", nx), rows("Hu", nu)
     p.rT = rows("HT", 2 * nx + nu)
     p.rZ, p.rZW = rows("HZ", nx), rows("HZW", nx)
-    for hk, Hk in (("hx", "Hx"), ("hu", "Hu"), ("hT", "HT"), ("hZ", "HZ"), ("hZW", "HZW")):
+    p.rTP = rows("HTP", nx + nu)
+    for hk, Hk in (("hx", "Hx"), ("hu", "Hu"), ("hT", "HT"), ("hZ", "HZ"), ("hZW", "HZW"), ("hTP", "HTP")):
         if d.get(Hk) is not None and np.asarray(d[hk]).size != np.asarray(d[Hk]).shape[0]:
             raise ValueError(f"{hk} / {Hk} row mismatch")
     return p, keep

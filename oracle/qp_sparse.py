@@ -79,7 +79,10 @@ def build_sparse_qp(p: dict, x_k, ref, variant: int = 0):
     x_k = np.asarray(x_k, dtype=np.float64).reshape(nx)
     ref = np.asarray(ref, dtype=np.float64).reshape(nx)
     received = variant == 1
-    L = Layout(nx, nu, N, aux=received)
+    # packet-received problem: the literal row :293 acts on free auxiliaries; with p['HTP'] (their
+    # elimination, include/tmpc.h) the rows act on [x_bar; u_bar] instead and no auxiliaries exist
+    projected = received and p.get("HTP") is not None and int(p.get("literal_terminal_row", 1)) == 1
+    L = Layout(nx, nu, N, aux=received and not projected)
     nv = L.nvar
 
     def sel(s):
@@ -122,11 +125,16 @@ def build_sparse_qp(p: dict, x_k, ref, variant: int = 0):
         h.append(hu)
     Aeq.append((A - np.eye(nx)) @ sel(L.xbar) + B @ sel(L.ubar))
     beq.append(np.zeros(nx))
-    if received:
+    if projected:
+        HTP, hTP = np.asarray(p["HTP"], dtype=np.float64), np.asarray(p["hTP"], dtype=np.float64)
+        G.append(HTP[:, :nx] @ sel(L.xbar) + HTP[:, nx:] @ sel(L.ubar))
+        h.append(hTP)
+    elif received:
         G.append(HT[:, :nx] @ sel(L.xaux) + HT[:, nx:2 * nx] @ sel(L.xbar) + HT[:, 2 * nx:] @ sel(L.uaux))
+        h.append(hT)
     else:
         G.append(HT[:, :nx] @ sel(L.x(N)) + HT[:, nx:2 * nx] @ sel(L.xbar) + HT[:, 2 * nx:] @ sel(L.ubar))
-    h.append(hT)
+        h.append(hT)
     return dict(P=Pq, q=q, c0=c0, A=np.vstack(Aeq), b=np.concatenate(beq),
                 G=np.vstack(G), h=np.concatenate(h), layout=L)
 

@@ -148,7 +148,9 @@ static void add_diff_quad(double *P, int nvar, int a, int b, const double *W, in
 static int build_sparse(const tmpc_problem *p, int variant, sparse_t *s) {
     const int nx = p->nx, nu = p->nu, N = p->N;
     const int received = (variant == 1);
-    const int aux = received && p->literal_terminal_row;
+    /* :293 literally = free auxiliaries; eliminated when the projection (HTP, hTP) is supplied (include/tmpc.h) */
+    const int projected = received && p->literal_terminal_row && p->rTP > 0 && p->HTP && p->hTP;
+    const int aux = received && p->literal_terminal_row && !projected;
     const int ox = 0, ou = nx * (N + 1), oxb = ou + nu * N, oub = oxb + nx, oxa = oub + nu, oua = oxa + nx;
     const int nvar = oub + nu + (aux ? nx + nu : 0);
     const int fixed = (!received) && p->fixed_x0;
@@ -156,7 +158,7 @@ static int build_sparse(const tmpc_problem *p, int variant, sparse_t *s) {
     const double *HZ = received ? p->HZW : p->HZ, *hZ = received ? p->hZW : p->hZ;
     if (rz > 0 && (!HZ || !hZ)) return -1;
     const int me = (fixed ? nx : 0) + nx * N + nx;
-    const int mi = rz + N * (p->rx + p->ru) + p->rT;
+    const int mi = rz + N * (p->rx + p->ru) + (projected ? p->rTP : p->rT);
     s->nvar = nvar; s->me = me; s->mi = mi;
     s->P = dalloc((size_t)nvar * nvar); s->Qr = dalloc((size_t)nvar * nx);
     s->Aeq = dalloc((size_t)me * nvar); s->Beq = dalloc((size_t)me * nx);
@@ -221,7 +223,14 @@ static int build_sparse(const tmpc_problem *p, int variant, sparse_t *s) {
     }
     er += nx;
     /* terminal */
-    {
+    if (projected) {
+        for (int r = 0; r < p->rTP; ++r) {
+            for (int j = 0; j < nx; ++j) s->G[(ir + r) * nvar + oxb + j] += p->HTP[r * (nx + nu) + j];
+            for (int j = 0; j < nu; ++j) s->G[(ir + r) * nvar + oub + j] += p->HTP[r * (nx + nu) + nx + j];
+            s->h0[ir + r] = p->hTP[r];
+        }
+        ir += p->rTP;
+    } else {
         const int cx = aux ? oxa : ox + N * nx, cu = aux ? oua : oub, w = 2 * nx + nu;
         for (int r = 0; r < p->rT; ++r) {
             for (int j = 0; j < nx; ++j) s->G[(ir + r) * nvar + cx + j] += p->HT[r * w + j];
@@ -471,6 +480,7 @@ static int polish(const form_t *f, work_t *w) {
                     for (int k = 0; k < m; ++k) v += Gs[(size_t)w->W[k] * nv + i] * w->y[k];
                     w->r1[i] = v;
                 }
+                if (getenv("ORACLE_DEBUG")) { double rn = 0; for (int i = 0; i < nv; ++i) if (fabs(w->r1[i]) > rn) rn = fabs(w->r1[i]); fprintf(stderr, "   polish it %d m %d step %d |r1| %.3e dmax %.3e\n", it, m, step, rn, dmax); }
                 for (int i = 0; i < nv; ++i) { double v = 0; for (int j = 0; j < nv; ++j) v += Hinv[i * nv + j] * w->r1[j]; w->t1[i] = v; }
                 for (int k = 0; k < m; ++k) {            /* dy rhs = r2 - G_W t1 */
                     const double *g = Gs + (size_t)w->W[k] * nv; double gz = 0, gt = 0;
@@ -499,6 +509,7 @@ static int polish(const form_t *f, work_t *w) {
             if (w->inW[i] && fabs(v) > 1e-11 * hi) ++nloose;    /* working-set row not on its bound: not converged */
         }
         for (int k = 0; k < m; ++k) if (w->y[k] < -1e-10 * ymax) ++nneg;
+        if (getenv("ORACLE_DEBUG")) fprintf(stderr, "   polish it %d m %d nviol %d nneg %d nloose %d\n", it, m, nviol, nneg, nloose);
         if (nloose) return 0;
         if (nviol == 0 && nneg == 0) {
             memcpy(w->z, w->zp, sizeof(double) * nv);

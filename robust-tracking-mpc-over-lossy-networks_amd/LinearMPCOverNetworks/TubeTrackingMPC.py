@@ -51,6 +51,8 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         self._computational_times = []
         self._Xf = self._Xc = self._Uc = None
         self._ZmW = None
+        self._XfP = None                               # terminal set of the packet-received problem, auxiliaries eliminated
+        self._eliminate_auxiliaries = True
         self._fixed_initial_state = False
         self._handle = None
         self._device = 0
@@ -113,6 +115,8 @@ class TubeTrackingMPC(TubeRegulatorMPC):
              "Uc_A": self._Uc.A, "Uc_b": self._Uc.b, "Xf_A": self._Xf.A, "Xf_b": self._Xf.b}
         if self._ZmW is not None:
             d["ZmW_A"], d["ZmW_b"] = self._ZmW.A, self._ZmW.b
+        if self._XfP is not None:
+            d["XfP_A"], d["XfP_b"] = self._XfP.A, self._XfP.b
         return d
 
     def setup_from_sets(self, sets: dict, fixed_initial_state: bool = False, create: bool = True):
@@ -122,6 +126,8 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         self._Xf = Polytope(sets["Xf_A"], sets["Xf_b"])
         if "ZmW_A" in sets:
             self._ZmW = Polytope(sets["ZmW_A"], sets["ZmW_b"])
+        if "XfP_A" in sets:
+            self._XfP = Polytope(sets["XfP_A"], sets["XfP_b"])
         self._fixed_initial_state = bool(fixed_initial_state)
         if create:
             self.generate_optimization_problem(fixed_initial_state)
@@ -219,6 +225,15 @@ class TubeTrackingMPC(TubeRegulatorMPC):
     def set_device(self, device: int):
         self._device = int(device)
 
+    def set_kernel_path(self, path: str):
+        """'auto' (default) | 'wave' | 'block' -- include/tmpc.h: tmpc_set_kernel_path."""
+        from . import _native
+        _native.set_kernel_path(self._handle, path)
+
+    def get_kernel_path(self, variant: int = 0) -> str:
+        from . import _native
+        return _native.get_kernel_path(self._handle, variant)
+
     def _close(self):
         if self._handle is not None:
             from . import _native
@@ -257,6 +272,12 @@ class ExtendedTubeTrackingMPC(TubeTrackingMPC):
         if self._ZmW is not None:
             d["extended"] = 1
             d["HZW"], d["hZW"] = self._ZmW.A, self._ZmW.b
+            if self._eliminate_auxiliaries:
+                # TubeTrackingMPC.py:293 puts the terminal rows on free variables of the other problem; what
+                # remains for this problem is x_bar in proj(Xf), computed once here (include/tmpc.h: HTP)
+                if self._XfP is None:
+                    self._XfP = up.eliminate_terminal_auxiliaries(self._Xf, self._A, self._B)
+                d["HTP"], d["hTP"] = self._XfP.A, self._XfP.b
         return d
 
     def solve_optimization_problem(self, x_init, ref, gamma_t=0):

@@ -12,10 +12,10 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libtmpc_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _PTR_FIELDS = ["A", "B", "Q", "R", "P", "T", "K", "K_anc",
-               "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW"]
+               "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW", "HTP", "hTP"]
 _INT_FIELDS = ["nx", "nu", "N", "rx", "ru", "rT", "rZ", "rZW",
                "fixed_x0", "extended", "literal_terminal_row", "max_iter"]
 
@@ -27,7 +27,7 @@ _up = C.POINTER(C.c_uint8)
 class TmpcProblem(C.Structure):
     """Field-for-field include/tmpc.h: tmpc_problem."""
     _fields_ = ([(n, C.c_int32) for n in _INT_FIELDS] + [("tol", C.c_double)]
-                + [(n, _dp) for n in _PTR_FIELDS])
+                + [(n, _dp) for n in _PTR_FIELDS] + [("rTP", C.c_int32)])
 
 
 _lib = None
@@ -83,6 +83,10 @@ def lib():
         L.tmpc_solve_batch_device.restype = C.c_int
         L.tmpc_set_stream_min_batch.argtypes = [C.c_void_p, C.c_int64]
         L.tmpc_set_stream_min_batch.restype = C.c_int
+        L.tmpc_set_kernel_path.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_set_kernel_path.restype = C.c_int
+        L.tmpc_get_kernel_path.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_get_kernel_path.restype = C.c_int
         L.tmpc_synchronize.argtypes = [C.c_void_p]
         L.tmpc_synchronize.restype = C.c_int
         L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -110,7 +114,7 @@ def pack_problem(d: dict):
     p.tol = float(d.get("tol", 0.0))
     square = {"A": (nx, nx), "B": (nx, nu), "Q": (nx, nx), "R": (nu, nu), "P": (nx, nx), "T": (nx, nx),
               "K": (nu, nx), "K_anc": (nu, nx)}
-    widths = {"Hx": nx, "Hu": nu, "HT": 2 * nx + nu, "HZ": nx, "HZW": nx}
+    widths = {"Hx": nx, "Hu": nu, "HT": 2 * nx + nu, "HZ": nx, "HZW": nx, "HTP": nx + nu}
     rows = {}
     for name in _PTR_FIELDS:
         v = d.get(name)
@@ -131,11 +135,12 @@ def pack_problem(d: dict):
             rows[name] = a.shape[0]
         keep.append(a)
         setattr(p, name, a.ctypes.data_as(_dp))
-    for hk, Hk in (("hx", "Hx"), ("hu", "Hu"), ("hT", "HT"), ("hZ", "HZ"), ("hZW", "HZW")):
+    for hk, Hk in (("hx", "Hx"), ("hu", "Hu"), ("hT", "HT"), ("hZ", "HZ"), ("hZW", "HZW"), ("hTP", "HTP")):
         if rows.get(hk, 0) != rows.get(Hk, 0):
             raise ValueError(f"{Hk} has {rows.get(Hk, 0)} rows but {hk} has {rows.get(hk, 0)} entries")
     p.rx, p.ru, p.rT = rows.get("Hx", 0), rows.get("Hu", 0), rows.get("HT", 0)
     p.rZ, p.rZW = rows.get("HZ", 0), rows.get("HZW", 0)
+    p.rTP = rows.get("HTP", 0)
     return p, keep
 
 
@@ -233,3 +238,20 @@ def set_stream_min_batch(h: Handle, min_batch: int):
     """Experimental streaming path for batches >= min_batch (<= 0: off)."""
     if lib().tmpc_set_stream_min_batch(h.ptr, int(min_batch)) != 0:
         raise RuntimeError(h.error())
+
+
+KERNEL_PATHS = {"auto": 0, "wave": 1, "block": 2}
+
+
+def set_kernel_path(h: Handle, path):
+    """include/tmpc.h: tmpc_set_kernel_path ('auto' | 'wave' | 'block')."""
+    code = KERNEL_PATHS[path] if isinstance(path, str) else int(path)
+    if lib().tmpc_set_kernel_path(h.ptr, code) != 0:
+        raise RuntimeError(h.error())
+
+
+def get_kernel_path(h: Handle, variant: int = 0) -> str:
+    code = lib().tmpc_get_kernel_path(h.ptr, int(variant))
+    if code < 0:
+        raise RuntimeError("tmpc_get_kernel_path failed")
+    return {v: k for k, v in KERNEL_PATHS.items()}[code]

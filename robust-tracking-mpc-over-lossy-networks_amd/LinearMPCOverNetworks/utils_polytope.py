@@ -284,3 +284,88 @@ def calculate_RPI(A, W, X, U, K, eps_var: float = 1e-4, s_max: int = 20,
     if return_container:
         return rpi, C, status
     return rpi, status
+
+
+def project_polytope(P, E, tol: float = 1e-9, max_vertices: int = 2000) -> Polytope:
+    """Exact H-representation of the linear image {E x : x in P} of a bounded polytope for a
+    low-dimensional image space (k = E.shape[0] <= 4): convex-hull method.  Support points of the
+    image are found by LPs over P; the hull of the points found so far is refined until every one
+    of its facets is a supporting hyperplane of the image (checked by one LP per facet).
+
+    Not in the reference (it keeps the projected-out variables in the QP, TubeTrackingMPC.py:293);
+    used to eliminate the free auxiliaries of the packet-received problem at set-up time."""
+    P = as_polytope(P)
+    E = np.atleast_2d(np.asarray(E, dtype=np.float64))
+    k = E.shape[0]
+
+    def sup(direction):
+        res = linprog(-(direction @ E), A_ub=P.A, b_ub=P.b, bounds=(None, None), method="highs")
+        if res.status != 0:
+            raise ValueError("projection: LP failed (status %d); polytope unbounded or empty?" % res.status)
+        return E @ res.x
+
+    if k == 1:
+        hi, lo = sup(np.array([1.0]))[0], sup(np.array([-1.0]))[0]
+        return Polytope([[1.0], [-1.0]], [hi, -lo], vertices=np.array([[lo], [hi]]))
+    pts = [sup(d) for d in np.r_[np.eye(k), -np.eye(k)]]
+    rng = np.random.default_rng(0)
+    while np.linalg.matrix_rank(np.array(pts)[1:] - pts[0], tol=1e-9) < k:
+        if len(pts) > 2 * k + 50:
+            raise ValueError("projection is not full dimensional")
+        d = rng.standard_normal(k)
+        pts.append(sup(d / np.linalg.norm(d)))
+    pts = np.unique(np.round(np.array(pts), 12), axis=0)
+    verified = set()
+    while True:
+        hull = ConvexHull(pts)
+        eq = hull.equations
+        _, idx = np.unique(np.round(eq, 10), axis=0, return_index=True)
+        eq = eq[np.sort(idx)]
+        added = False
+        for row in eq:
+            key = tuple(np.round(row, 9))
+            if key in verified:
+                continue
+            a, b = row[:-1], -row[-1]
+            y = sup(a)
+            if a @ y > b + tol * max(1.0, abs(b)):
+                pts = np.vstack([pts, y])
+                added = True
+            else:
+                verified.add(key)
+        if not added:
+            return Polytope(eq[:, :-1], -eq[:, -1], vertices=pts[hull.vertices])
+        if len(pts) > max_vertices:
+            raise ValueError("projection: more than %d vertices" % max_vertices)
+
+
+def steady_state_basis(A, B) -> np.ndarray:
+    """Orthonormal basis N ((nx+nu) x nu) of {(x_bar, u_bar) : (A - I) x_bar + B u_bar = 0}
+    (TubeTrackingMPC.py:147)."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64).reshape(A.shape[0], -1)
+    M = np.c_[A - np.eye(A.shape[0]), B]
+    _, s, Vt = np.linalg.svd(M)
+    rank = int(np.sum(s > 1e-10 * s[0]))
+    return Vt[rank:].T
+
+
+def eliminate_terminal_auxiliaries(Xf, A, B) -> Polytope:
+    """Terminal constraint of the packet-received problem with its free variables eliminated.
+
+    TubeTrackingMPC.py:293 writes  HT_x x_N' + HT_xbar x_bar + HT_u u_bar' <= hT  on the BASE problem's
+    x_N' and u_bar', which the packet-received problem neither constrains otherwise nor prices: they are
+    free auxiliaries and the row block only says  x_bar in proj_xbar(Xf).  Together with the steady-state
+    equation (x_bar, u_bar) = N phi this is a polytope in phi (dimension nu), computed here exactly and
+    returned as rows acting on [x_bar; u_bar] (valid on the steady-state subspace)."""
+    Xf = as_polytope(Xf)
+    A = np.asarray(A, dtype=np.float64)
+    nx = A.shape[0]
+    Nss = steady_state_basis(A, B)
+    nu = Nss.shape[0] - nx
+    HT = Xf.A
+    # variables (x_aux, u_aux, phi)
+    rows = np.c_[HT[:, :nx], HT[:, 2 * nx:], HT[:, nx:2 * nx] @ Nss[:nx]]
+    E = np.c_[np.zeros((Nss.shape[1], nx + nu)), np.eye(Nss.shape[1])]
+    Pphi = project_polytope(Polytope(rows, Xf.b), E)
+    return Polytope(Pphi.A @ Nss.T, Pphi.b)

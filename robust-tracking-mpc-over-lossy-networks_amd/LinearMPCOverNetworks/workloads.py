@@ -43,3 +43,16 @@ def double_integrator():
     W = box2poly([[-0.1, 0.1]] * 2)
     return dict(A=A, B=B, Q=np.eye(2), R=np.eye(1), X=X, U=U, W=W,
                 w_bound=np.array([0.1, 0.1]), name="double_integrator")
+
+
+def synthetic(n: int = 12, m: int = 4, seed: int = 5):
+    """Random stable model of BASELINE.json config 5 (not in the reference):
+    A = 0.95 A0 / rho(A0), A0 ~ N(0,1)^(n x n), B ~ N(0,1)^(n x m); Q = I, R = 0.1 I;
+    X = +-10, U = +-1, W = +-0.01 boxes."""
+    rng = np.random.default_rng(seed)
+    A0 = rng.standard_normal((n, n))
+    A = 0.95 * A0 / np.max(np.abs(np.linalg.eigvals(A0)))
+    B = rng.standard_normal((n, m))
+    w = 0.01 * np.ones(n)
+    return dict(A=A, B=B, Q=np.eye(n), R=0.1 * np.eye(m), X=box2poly([[-10.0, 10.0]] * n), U=box2poly([[-1.0, 1.0]] * m),
+                W=box2poly(np.c_[-w, w]), w_bound=w, name="synthetic")

@@ -24,6 +24,10 @@ struct Variant {
     tmpc::KernelShape shape;
     tmpc::StreamQP sq{};
     bool stream_ok = false;
+    bool wave_ok = false;        // a compiled one-wave-per-QP shape covers this variant
+    tmpc::DeviceQP db{};         // same model with Hs / Hinv padded for the block kernel
+    tmpc::BlockQP bq{};
+    int tiles = 0;               // block kernel: NVP / 16 (0: not available)
     std::vector<void *> dev;     // device allocations of this variant
 };
 
@@ -46,6 +50,10 @@ struct tmpc_handle {
     int ws_ncp = 0;
     double *ws_s = nullptr, *ws_lam = nullptr, *ws_z = nullptr;
     int32_t *ws_stat = nullptr, *ws_it = nullptr;
+    int kernel_path = TMPC_PATH_AUTO;
+    int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
+    int blk_ncp = 0;
+    double *blk_ws = nullptr;
     int64_t stream_min_batch = INT64_MAX;   // streaming path is opt-in (tmpc_set_stream_min_batch); see DESIGN.md 5.3
     // staging buffers for the host-pointer entry point
     int64_t cap = 0;
@@ -76,24 +84,48 @@ int upload(tmpc_handle *h, Variant &v, const T *src, size_t n, const T **dst) {
     return TMPC_OK;
 }
 
-int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
+int upload_common(tmpc_handle *h, Variant &v, const tmpc_problem &p, tmpc::DeviceQP &d, int NVP) {
+    const tmpc::Condensed &c = v.c;
+    const int nx = c.nx;
+    std::vector<double> Hs(static_cast<size_t>(NVP) * NVP, 0.0), Hinv(Hs.size(), 0.0);
+    for (int i = 0; i < NVP; ++i)
+        for (int j = 0; j < NVP; ++j) {
+            const bool in = i < c.nv && j < c.nv;
+            Hs[static_cast<size_t>(i) * NVP + j] = in ? c.Hs(i, j) : (i == j ? 1.0 : 0.0);
+            Hinv[static_cast<size_t>(i) * NVP + j] = in ? c.Hinv(i, j) : (i == j ? 1.0 : 0.0);
+        }
+    d.nx = c.nx; d.nu = c.nu; d.N = c.N; d.nv = c.nv; d.nc = c.nc; d.npar = c.npar; d.nth = c.nth;
+    d.off_theta = c.off_theta; d.off_x0 = c.off_x0; d.off_aux = c.off_aux;
+    d.max_iter = p.max_iter > 0 ? p.max_iter : 60;
+    d.tol = p.tol > 0 ? p.tol : 1e-7;
+    d.always_infeasible = c.always_infeasible ? 1 : 0;
+    d.dbg = nullptr;
+    int rc;
+    if ((rc = upload(h, v, Hs.data(), Hs.size(), &d.Hs))) return rc;
+    if ((rc = upload(h, v, Hinv.data(), Hinv.size(), &d.Hinv))) return rc;
+    if ((rc = upload(h, v, c.F1s.a.data(), c.F1s.a.size(), &d.F1s))) return rc;
+    if ((rc = upload(h, v, c.F2s.a.data(), c.F2s.a.size(), &d.F2s))) return rc;
+    if ((rc = upload(h, v, c.gp0.data(), c.gp0.size(), &d.gp0))) return rc;
+    if ((rc = upload(h, v, c.Ep.a.data(), c.Ep.a.size(), &d.Ep))) return rc;
+    if ((rc = upload(h, v, c.Dv.data(), c.Dv.size(), &d.Dv))) return rc;
+    if ((rc = upload(h, v, c.Mth.a.data(), c.Mth.a.size(), &d.Mth))) return rc;
+    if ((rc = upload(h, v, p.A, static_cast<size_t>(nx) * nx, &d.A))) return rc;
+    if ((rc = upload(h, v, p.B, static_cast<size_t>(nx) * c.nu, &d.B))) return rc;
+    return TMPC_OK;
+}
+
+// one-wave-per-QP path (tmpc_kernels.hip): slot layout, factored terminal block
+int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const tmpc::Condensed &c = v.c;
     int nd = c.nd, ncc = c.ncc, kc = c.kc;
     if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) {
         nd = c.nc; ncc = 0; kc = 0;                       // no factored shape compiled: all rows dense
-        if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) {
-            char buf[200];
-            std::snprintf(buf, sizeof buf, "condensed QP (nv=%d, rows=%d of which %d factored with width %d) is outside the compiled kernel shapes",
-                          c.nv, c.nc, c.ncc, c.kc);
-            h->err = buf;
-            return TMPC_E_UNSUPPORTED;
-        }
+        if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) return TMPC_OK;      // wave_ok stays false
     }
     const int NVP = v.shape.nvp, NDP = v.shape.rd * 64, KCP = v.shape.kcp, NCCP = v.shape.rc * 64, nx = c.nx;
     const int slots = (v.shape.rd + v.shape.rc) * 64;
     std::vector<double> Gt(static_cast<size_t>(NVP) * NDP, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
-        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), Hs(static_cast<size_t>(NVP) * NVP, 0.0), Hinv(Hs.size(), 0.0),
-        g0p(slots, 1.0), Esp(static_cast<size_t>(slots) * nx, 0.0);
+        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), g0p(slots, 1.0), Esp(static_cast<size_t>(slots) * nx, 0.0);
     for (int r = 0; r < nd; ++r)
         for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NDP + r] = c.Gs(r, j);
     for (int r = 0; r < ncc; ++r)
@@ -105,35 +137,15 @@ int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         g0p[slot] = c.g0s[r];
         for (int j = 0; j < nx; ++j) Esp[static_cast<size_t>(slot) * nx + j] = c.Es(r, j);
     }
-    for (int i = 0; i < NVP; ++i)
-        for (int j = 0; j < NVP; ++j) {
-            const bool in = i < c.nv && j < c.nv;
-            Hs[static_cast<size_t>(i) * NVP + j] = in ? c.Hs(i, j) : (i == j ? 1.0 : 0.0);
-            Hinv[static_cast<size_t>(i) * NVP + j] = in ? c.Hinv(i, j) : (i == j ? 1.0 : 0.0);
-        }
     tmpc::DeviceQP &d = v.d;
-    d.nx = c.nx; d.nu = c.nu; d.N = c.N; d.nv = c.nv; d.nc = c.nc; d.npar = c.npar; d.nth = c.nth;
-    d.nd = nd; d.ncc = ncc; d.kc = kc;
-    d.off_theta = c.off_theta; d.off_x0 = c.off_x0; d.off_aux = c.off_aux;
-    d.max_iter = p.max_iter > 0 ? p.max_iter : 60;
-    d.tol = p.tol > 0 ? p.tol : 1e-7;
-    d.always_infeasible = c.always_infeasible ? 1 : 0;
     int rc;
+    if ((rc = upload_common(h, v, p, d, NVP))) return rc;
+    d.nd = nd; d.ncc = ncc; d.kc = kc;
     if ((rc = upload(h, v, Gt.data(), Gt.size(), &d.Gt))) return rc;
     if ((rc = upload(h, v, Hct.data(), Hct.size(), &d.Hct))) return rc;
     if ((rc = upload(h, v, Psi.data(), Psi.size(), &d.Psi))) return rc;
-    if ((rc = upload(h, v, Hs.data(), Hs.size(), &d.Hs))) return rc;
-    if ((rc = upload(h, v, Hinv.data(), Hinv.size(), &d.Hinv))) return rc;
-    if ((rc = upload(h, v, c.F1s.a.data(), c.F1s.a.size(), &d.F1s))) return rc;
-    if ((rc = upload(h, v, c.F2s.a.data(), c.F2s.a.size(), &d.F2s))) return rc;
     if ((rc = upload(h, v, g0p.data(), g0p.size(), &d.g0p))) return rc;
     if ((rc = upload(h, v, Esp.data(), Esp.size(), &d.Esp))) return rc;
-    if ((rc = upload(h, v, c.gp0.data(), c.gp0.size(), &d.gp0))) return rc;
-    if ((rc = upload(h, v, c.Ep.a.data(), c.Ep.a.size(), &d.Ep))) return rc;
-    if ((rc = upload(h, v, c.Dv.data(), c.Dv.size(), &d.Dv))) return rc;
-    if ((rc = upload(h, v, c.Mth.a.data(), c.Mth.a.size(), &d.Mth))) return rc;
-    if ((rc = upload(h, v, p.A, static_cast<size_t>(nx) * nx, &d.A))) return rc;
-    if ((rc = upload(h, v, p.B, static_cast<size_t>(nx) * c.nu, &d.B))) return rc;
     // streaming path: every row dense, row order of Condensed::Gs
     {
         const int ncp = (c.nc + 63) / 64 * 64;
@@ -151,7 +163,6 @@ int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
             if ((rc = upload(h, v, Esd.data(), Esd.size(), &v.sq.Esd))) return rc;
         }
     }
-    d.dbg = nullptr;
 #ifdef TMPC_STAMPS
     {
         void *dbgp = nullptr;
@@ -161,7 +172,77 @@ int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         d.dbg = static_cast<long long *>(dbgp);
     }
 #endif
+    v.wave_ok = true;
     return TMPC_OK;
+}
+
+// workgroup-per-QP path (tmpc_block.hip): every row dense, nv padded to a multiple of 16
+int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
+    const tmpc::Condensed &c = v.c;
+    v.tiles = tmpc::block_tiles(c.nv);
+    if (v.tiles == 0) return TMPC_OK;
+    const int NVP = 16 * v.tiles, nx = c.nx, ncp = (c.nc + 63) / 64 * 64;
+    std::vector<double> Grm(static_cast<size_t>(ncp) * NVP, 0.0), Gcm(Grm.size(), 0.0), GH(Grm.size(), 0.0), g0(ncp, 1.0),
+        Es(static_cast<size_t>(ncp) * nx, 0.0);
+    for (int r = 0; r < c.nc; ++r) {
+        for (int j = 0; j < c.nv; ++j) {
+            const double g = c.Gs(r, j);
+            Grm[static_cast<size_t>(r) * NVP + j] = g;
+            Gcm[static_cast<size_t>(j) * ncp + r] = g;
+            double t = 0.0;
+            for (int k = 0; k < c.nv; ++k) t += c.Gs(r, k) * c.Hinv(k, j);
+            GH[static_cast<size_t>(r) * NVP + j] = t;
+        }
+        g0[r] = c.g0s[r];
+        for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(r) * nx + j] = c.Es(r, j);
+    }
+    int rc;
+    if ((rc = upload_common(h, v, p, v.db, NVP))) return rc;
+    v.db.nd = c.nc; v.db.ncc = 0; v.db.kc = 0;
+    v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = nullptr;
+    v.bq.ncp = ncp;
+    if ((rc = upload(h, v, Grm.data(), Grm.size(), &v.bq.Grm))) return rc;
+    if ((rc = upload(h, v, Gcm.data(), Gcm.size(), &v.bq.Gcm))) return rc;
+    if ((rc = upload(h, v, GH.data(), GH.size(), &v.bq.GHrm))) return rc;
+    if ((rc = upload(h, v, g0.data(), g0.size(), &v.bq.g0))) return rc;
+    if ((rc = upload(h, v, Es.data(), Es.size(), &v.bq.Es))) return rc;
+    return TMPC_OK;
+}
+
+int upload_variant(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
+    int rc;
+    if ((rc = upload_wave(h, v, p))) return rc;
+    if ((rc = upload_block(h, v, p))) return rc;
+    if (!v.wave_ok && v.tiles == 0) {
+        char buf[200];
+        std::snprintf(buf, sizeof buf, "condensed QP (nv=%d, rows=%d) is outside the compiled kernels (nv <= 128)", v.c.nv, v.c.nc);
+        h->err = buf;
+        return TMPC_E_UNSUPPORTED;
+    }
+    return TMPC_OK;
+}
+
+// block-kernel workspace: one slice per resident workgroup
+int ensure_block_ws(tmpc_handle *h) {
+    int ncp = 0, occ = 64;
+    for (int k = 0; k < h->nvariants; ++k)
+        if (h->v[k].tiles) { ncp = std::max(ncp, h->v[k].bq.ncp); occ = std::min(occ, tmpc::block_occupancy(h->v[k].tiles)); }
+    if (ncp == 0 || h->blk_ws) return TMPC_OK;
+    int occ_max = 1;
+    for (int k = 0; k < h->nvariants; ++k)
+        if (h->v[k].tiles) occ_max = std::max(occ_max, tmpc::block_occupancy(h->v[k].tiles));
+    const int blocks = h->n_cu * occ_max;
+    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->blk_ws),
+                         static_cast<size_t>(blocks) * tmpc::block_workspace_rows() * ncp * sizeof(double)));
+    h->blk_blocks = blocks;
+    h->blk_ncp = ncp;
+    return TMPC_OK;
+}
+
+bool use_block(const tmpc_handle *h, const Variant &v) {
+    if (h->kernel_path == TMPC_PATH_BLOCK) return v.tiles != 0;
+    if (h->kernel_path == TMPC_PATH_WAVE) return !v.wave_ok;
+    return !v.wave_ok;
 }
 
 void free_staging(tmpc_handle *h) {
@@ -208,6 +289,14 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     for (int k = 0; k < h->nvariants; ++k) {
         if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
         Variant &v = h->v[k];
+        if (use_block(h, v)) {
+            int rcw = ensure_block_ws(h);
+            if (rcw) return rcw;
+            // the workspace slices are sized for the largest variant; a slice is addressed with this variant's ncp
+            HIP_TRY(h, tmpc::launch_block(v.db, v.bq, v.tiles, h->blk_ws, h->blk_blocks, k, B, x_k, ref, variant, u_nom, x_nom0,
+                                          xu_ss, x_nom, status, iters, h->stream));
+            continue;
+        }
         tmpc::WarmStart warm{};
         if (v.stream_ok && B >= h->stream_min_batch) {
             // large batch: 16-lane-per-QP streaming iteration first, refinement by the wave-per-QP kernel
@@ -310,7 +399,7 @@ void tmpc_destroy(tmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
     {
-        void *wsp[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it};
+        void *wsp[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it, h->blk_ws};
         for (void *q2 : wsp) if (q2) (void)hipFree(q2);
     }
     for (int k = 0; k < 2; ++k)
@@ -363,6 +452,23 @@ int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch) {
     if (!h) return TMPC_E_INVALID;
     h->stream_min_batch = min_batch > 0 ? min_batch : INT64_MAX;
     return TMPC_OK;
+}
+
+int tmpc_set_kernel_path(tmpc_handle *h, int path) {
+    if (!h) return TMPC_E_INVALID;
+    if (path != TMPC_PATH_AUTO && path != TMPC_PATH_WAVE && path != TMPC_PATH_BLOCK) { h->err = "tmpc_set_kernel_path: unknown path"; return TMPC_E_INVALID; }
+    for (int k = 0; k < h->nvariants; ++k) {
+        if (path == TMPC_PATH_WAVE && !h->v[k].wave_ok && h->device >= 0) { h->err = "tmpc_set_kernel_path: no wave-per-QP shape covers this problem"; return TMPC_E_UNSUPPORTED; }
+        if (path == TMPC_PATH_BLOCK && h->v[k].tiles == 0 && h->device >= 0) { h->err = "tmpc_set_kernel_path: the block kernel needs nv <= 128"; return TMPC_E_UNSUPPORTED; }
+    }
+    h->kernel_path = path;
+    return TMPC_OK;
+}
+
+int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
+    if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    if (h->device < 0) return TMPC_PATH_AUTO;
+    return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;
 }
 
 int tmpc_synchronize(tmpc_handle *h) {

@@ -1,0 +1,755 @@
+// Workgroup-per-QP solve kernel for gfx950 (MI355X): the general path for condensed QPs that do
+// not fit the one-wave-per-QP kernel of tmpc_kernels.hip -- up to 128 decision variables, any
+// number of inequality rows (cartpole N = 20, the extended controller's packet-received problem
+// with its Z (-) W rows, the synthetic n = 12, m = 4, N = 30 model of BASELINE.json config 5).
+//
+// Same algorithm as tmpc_kernels.hip / oracle (unconstrained-minimiser
+// shortcut, Mehrotra predictor-corrector interior point on the normal equations, active-set
+// refinement by proximal Newton steps), different mapping to the machine:
+//
+//   * one workgroup of 256 threads (4 waves) per QP instance, persistent, grid-stride over the batch;
+//   * the per-row state (s, lambda, r_p, d, ...) lives in a per-workgroup workspace in HBM/L2, laid
+//     out [quantity][row]: thread t owns rows t, t+256, ...; every access is a coalesced stream and
+//     the register footprint does not depend on the number of rows, so several workgroups share a CU;
+//   * M = Hs + G'DG -- nc*nv^2 of the ~nc*nv^2 + nv^3/3 flops of an iteration -- is formed with
+//     v_mfma_f64_16x16x4_f64: A = (d .* G)' and B = G are read straight from the row-major copy of G
+//     (one f64 per lane and k-step, 4 x 128 B segments per load), the 16x16 tiles of the lower
+//     triangle are spread over the four waves (tile rows g and T-1-g per group; for small nv the
+//     waves also split the rows and add their partial tiles in LDS);
+//   * M is factored in LDS by the whole workgroup (right-looking Cholesky), the triangular solves
+//     run in wave 0 with the right-hand side held one/two entries per lane (v_readlane broadcast);
+//   * G'v products (two vectors per pass) use thread-per-(column, row part) over the row-major
+//     copy; G v products thread-per-row over the column-major copy; G z itself is carried along
+//     incrementally (G z += alpha G dz).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "tmpc_device.hpp"
+#include "tmpc_wave.hpp"
+
+namespace tmpc {
+
+namespace {
+
+using namespace wv;
+
+constexpr int BT = 256;          // threads per workgroup
+constexpr int BW = BT / WAVE;    // waves per workgroup
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// rows of the per-workgroup workspace, each [ncp] doubles
+enum { WS_S, WS_LAM, WS_H, WS_GZ, WS_RP, WS_D, WS_V1, WS_W, WS_C1, WS_RS, WS_DS, WS_DL, WS_GDZ, WS_Y, WS_RR, WS_INW, WS_COUNT };
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int T>
+struct BShape {
+    static constexpr int NVP = 16 * T;
+    static constexpr int LDM = NVP + 1;                              // odd stride: conflict-free column walks
+    static constexpr int WCAP = NVP >= 128 ? 128 : NVP + 16;         // working-set rows of the refinement
+    static constexpr int LDSS = WCAP + 1;
+    static constexpr int BIG = cmax(NVP * LDM, WCAP * LDSS);         // M / its factor, later S / its factor
+    static constexpr int PARTS = BT / NVP;                           // row parts of a G'v pass
+    static constexpr int G = T >= 2 ? T / 2 : 1;                     // tile groups of the MFMA pass
+    static constexpr int RSPLIT = BW / G;                            // row parts of the MFMA pass
+    static constexpr int NVEC = 10;                                  // nv-vectors
+    static constexpr int SMALL = NVEC * NVP + 2 * BT + 2 * WCAP + cmax(NVP, WCAP) + WCAP /*Widx as ints, padded*/ + 32 + 32;
+    static constexpr int TOTAL = BIG + SMALL;
+    // resident workgroups per CU the LDS footprint allows (capped at 4) = waves per SIMD the register budget is set for
+    static constexpr int OCC = (160 * 1024 / 8) / TOTAL >= 2 ? 2 : 1;
+};
+
+template <class OpA, class OpB, class OpC>
+__device__ __forceinline__ void block_reduce3(double &a, double &b, double &c, double *red, int wave, int lane) {
+    a = wave_reduce<OpA>(a);
+    b = wave_reduce<OpB>(b);
+    c = wave_reduce<OpC>(c);
+    __syncthreads();
+    if (lane == 0) { red[wave] = a; red[BW + wave] = b; red[2 * BW + wave] = c; }
+    __syncthreads();
+    a = OpA::f(OpA::f(red[0], red[1]), OpA::f(red[2], red[3]));
+    b = OpB::f(OpB::f(red[BW + 0], red[BW + 1]), OpB::f(red[BW + 2], red[BW + 3]));
+    c = OpC::f(OpC::f(red[2 * BW + 0], red[2 * BW + 1]), OpC::f(red[2 * BW + 2], red[2 * BW + 3]));
+}
+template <class Op>
+__device__ __forceinline__ double block_reduce1(double a, double *red, int wave, int lane) {
+    a = wave_reduce<Op>(a);
+    __syncthreads();
+    if (lane == 0) red[wave] = a;
+    __syncthreads();
+    return Op::f(Op::f(red[0], red[1]), Op::f(red[2], red[3]));
+}
+
+// G_row(r) . v for the thread's row: column-major copy, v in LDS (broadcast reads)
+__device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v) {
+    double t0 = 0.0, t1 = 0.0;
+    int j = 0;
+    for (; j + 1 < nv; j += 2) {
+        t0 = fma(Gcm[static_cast<size_t>(j) * ncp + r], v[j], t0);
+        t1 = fma(Gcm[static_cast<size_t>(j + 1) * ncp + r], v[j + 1], t1);
+    }
+    if (j < nv) t0 = fma(Gcm[static_cast<size_t>(j) * ncp + r], v[j], t0);
+    return t0 + t1;
+}
+
+// out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
+template <int T>
+__device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
+                                            double *parts, double *out_a, double *out_b, int tid) {
+    constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS;
+    const int j = tid % NVP, part = tid / NVP;
+    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+    int r = part;
+    for (; r + PARTS < nc; r += 2 * PARTS) {
+        const double g0 = Grm[static_cast<size_t>(r) * NVP + j], g1 = Grm[static_cast<size_t>(r + PARTS) * NVP + j];
+        a0 = fma(g0, va[r], a0); b0 = fma(g0, vb[r], b0);
+        a1 = fma(g1, va[r + PARTS], a1); b1 = fma(g1, vb[r + PARTS], b1);
+    }
+    if (r < nc) {
+        const double g0 = Grm[static_cast<size_t>(r) * NVP + j];
+        a0 = fma(g0, va[r], a0); b0 = fma(g0, vb[r], b0);
+    }
+    __syncthreads();                       // previous readers of `parts` are done
+    parts[part * NVP + j] = a0 + a1;
+    parts[BT + part * NVP + j] = b0 + b1;
+    __syncthreads();
+    if (tid < NVP) {
+        double sa = 0.0, sb = 0.0;
+#pragma unroll
+        for (int p = 0; p < PARTS; ++p) { sa += parts[p * NVP + tid]; sb += parts[BT + p * NVP + tid]; }
+        out_a[tid] = sa;
+        out_b[tid] = sb;
+    }
+    __syncthreads();
+}
+
+// Tiles of the lower triangle of G'DG owned by tile group GI (tile rows RA = GI and RB = T-1-GI),
+// accumulated over the k-steps (4 rows each) rpart, rpart + RSPLIT, ... and added into M (LDS).
+template <int T, int GI>
+__device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int nsteps, int rpart,
+                                          double *M, int lane) {
+    using SH = BShape<T>;
+    constexpr int NVP = SH::NVP, LDM = SH::LDM, RS = SH::RSPLIT;
+    constexpr int RA = T == 1 ? 0 : GI, RB = T == 1 ? 0 : T - 1 - GI;
+    constexpr int NA = T == 1 ? 0 : RA + 1, NB = RB + 1;
+    constexpr int NAA = NA > 0 ? NA : 1;
+    v4d accA[NAA], accB[NB];
+#pragma unroll
+    for (int t = 0; t < NAA; ++t) accA[t] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NB; ++t) accB[t] = v4d{0.0, 0.0, 0.0, 0.0};
+    const int kq = lane >> 4, c = lane & 15;
+    double cur[NB], nxt[NB];
+    double dcur = 0.0, dnxt = 0.0;
+    int ks = rpart;
+    if (ks < nsteps) {
+        const size_t row = static_cast<size_t>(4 * ks + kq);
+#pragma unroll
+        for (int t = 0; t < NB; ++t) cur[t] = Grm[row * NVP + 16 * t + c];
+        dcur = dvec[row];
+    }
+    for (; ks < nsteps; ks += RS) {
+        const int kn = ks + RS;
+        if (kn < nsteps) {
+            const size_t row = static_cast<size_t>(4 * kn + kq);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) nxt[t] = Grm[row * NVP + 16 * t + c];
+            dnxt = dvec[row];
+        }
+        const double aB = dcur * cur[RB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, cur[t], accB[t], 0, 0, 0);
+        if constexpr (NA > 0) {
+            const double aA = dcur * cur[RA];
+#pragma unroll
+            for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, cur[t], accA[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t) cur[t] = nxt[t];
+        dcur = dnxt;
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int p = 0; p < RS; ++p) {
+        if (rpart == p) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) M[(16 * RB + kq + 4 * reg) * LDM + 16 * t + c] += accB[t][reg];
+            if constexpr (NA > 0) {
+#pragma unroll
+                for (int t = 0; t < NA; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) M[(16 * RA + kq + 4 * reg) * LDM + 16 * t + c] += accA[t][reg];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int T>
+__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, int nsteps, double *M,
+                                        int wave, int lane) {
+    constexpr int G = BShape<T>::G;
+    const int g = wave % G, rpart = wave / G;
+    if constexpr (G == 1) {
+        gdg_group<T, 0>(Grm, dvec, nsteps, rpart, M, lane);
+    } else if constexpr (G == 2) {
+        if (g == 0) gdg_group<T, 0>(Grm, dvec, nsteps, rpart, M, lane);
+        else gdg_group<T, 1>(Grm, dvec, nsteps, rpart, M, lane);
+    } else {
+        if (g == 0) gdg_group<T, 0>(Grm, dvec, nsteps, rpart, M, lane);
+        else if (g == 1) gdg_group<T, 1>(Grm, dvec, nsteps, rpart, M, lane);
+        else if (g == 2) gdg_group<T, 2>(Grm, dvec, nsteps, rpart, M, lane);
+        else gdg_group<T, 3>(Grm, dvec, nsteps, rpart, M, lane);
+    }
+}
+
+// Right-looking Cholesky of the n x n lower triangle at Mx (LDS, row stride ld) by the whole
+// workgroup.  The diagonal is left untouched; dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a
+// non-positive pivot.
+__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, int tid) {
+    const int tx = tid & 15, ty = tid >> 4;
+    for (int j = 0; j < n; ++j) {
+        __syncthreads();
+        const double pjj = Mx[j * ld + j];
+        if (!(pjj > 0.0)) return false;
+        const double inv = 1.0 / sqrt(pjj);
+        const int n1 = n - j - 1;
+        for (int i = tid; i < n1; i += BT) Mx[(j + 1 + i) * ld + j] *= inv;
+        if (tid == 0) dinv[j] = inv;
+        __syncthreads();
+        for (int ri = ty; ri < n1; ri += 16) {
+            const double lij = Mx[(j + 1 + ri) * ld + j];
+            for (int ck = tx; ck <= ri; ck += 16) Mx[(j + 1 + ri) * ld + j + 1 + ck] -= lij * Mx[(j + 1 + ck) * ld + j];
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// L L' x = b in one wave (n <= 128): lane l holds entries l and l + 64.  b and x may alias.
+__device__ __forceinline__ void wave_llt_solve(const double *L, int ld, int n, const double *dinv, const double *b, double *x, int lane,
+                                               int nfill = 0) {
+    const int i0 = lane, i1 = lane + WAVE;
+    double b0 = i0 < n ? b[i0] : 0.0, b1 = i1 < n ? b[i1] : 0.0;
+    for (int j = 0; j < n; ++j) {
+        const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
+        const double yj = bj * dinv[j];
+        if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = yj; else b1 = yj; }
+        if (i0 > j && i0 < n) b0 = fma(-L[i0 * ld + j], yj, b0);
+        if (i1 > j && i1 < n) b1 = fma(-L[i1 * ld + j], yj, b1);
+    }
+    for (int j = n - 1; j >= 0; --j) {
+        const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
+        const double xj = bj * dinv[j];
+        if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = xj; else b1 = xj; }
+        if (i0 < j) b0 = fma(-L[j * ld + i0], xj, b0);
+        if (i1 < j) b1 = fma(-L[j * ld + i1], xj, b1);
+    }
+    if (i0 < n) x[i0] = b0; else if (i0 < nfill) x[i0] = 0.0;      // entries n..nfill-1 (padding) are cleared
+    if (i1 < n) x[i1] = b1; else if (i1 < nfill) x[i1] = 0.0;
+}
+
+template <int T>
+__global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
+    const DeviceQP qp, const BlockQP bq, double *__restrict__ ws, const int variant_id, const int64_t B,
+    const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
+    double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
+    double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
+    using SH = BShape<T>;
+    constexpr int NVP = SH::NVP, LDM = SH::LDM, WCAP = SH::WCAP, LDSS = SH::LDSS;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double *big = smem;
+    double *qv = big + SH::BIG;          // linear term
+    double *zv = qv + NVP;               // z
+    double *cgv = zv + NVP;              // cost gradient, later the corrector's right-hand side
+    double *rhsv = cgv + NVP;            // predictor right-hand side
+    double *dzav = rhsv + NVP;           // affine direction
+    double *dzv = dzav + NVP;            // final direction
+    double *zpv = dzv + NVP;             // refinement iterate
+    double *tv = zpv + NVP;              // scratch
+    double *uv = tv + NVP;               // scratch
+    double *glv = uv + NVP;              // G' lambda
+    double *parts = glv + NVP;           // [2][BT] partial sums of a G'v pass
+    double *yv = parts + 2 * BT;         // [WCAP]
+    double *dyv = yv + WCAP;             // [WCAP]
+    double *dinv = dyv + WCAP;           // [max(NVP, WCAP)] reciprocal pivots
+    int *Widx = reinterpret_cast<int *>(dinv + cmax(NVP, WCAP));   // [WCAP] (ints in a WCAP-double slot)
+    double *xin = reinterpret_cast<double *>(Widx) + WCAP;          // [32] x_k | ref
+    double *red = xin + 32;                                          // [32] reductions / broadcasts
+    int *ibc = reinterpret_cast<int *>(red + 24);                    // a few ints
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int nx = qp.nx, nu = qp.nu, N = qp.N, nv = qp.nv, nc = qp.nc, ncp = bq.ncp;
+    const double *__restrict__ Grm = bq.Grm;
+    const double *__restrict__ Gcm = bq.Gcm;
+    const double *__restrict__ GHrm = bq.GHrm;
+    const int nsteps = (nc + 3) / 4;
+
+    double *W0 = ws + static_cast<size_t>(blockIdx.x) * WS_COUNT * ncp;
+    double *s_ = W0 + WS_S * ncp, *lam_ = W0 + WS_LAM * ncp, *h_ = W0 + WS_H * ncp, *gz_ = W0 + WS_GZ * ncp;
+    double *rp_ = W0 + WS_RP * ncp, *d_ = W0 + WS_D * ncp, *v1_ = W0 + WS_V1 * ncp, *w_ = W0 + WS_W * ncp;
+    double *c1_ = W0 + WS_C1 * ncp, *rs_ = W0 + WS_RS * ncp, *ds_ = W0 + WS_DS * ncp, *dl_ = W0 + WS_DL * ncp;
+    double *gdz_ = W0 + WS_GDZ * ncp, *yall_ = W0 + WS_Y * ncp, *rr_ = W0 + WS_RR * ncp;
+    int *inW_ = reinterpret_cast<int *>(W0 + WS_INW * ncp);
+
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        if (variant != nullptr && variant[b] != variant_id) continue;
+        if (variant == nullptr && variant_id != 0) continue;
+        __syncthreads();
+        if (tid < nx) { xin[tid] = x_k[b * nx + tid]; xin[16 + tid] = ref[b * nx + tid]; }
+        __syncthreads();
+        int st = TMPC_STATUS_MAX_ITER;
+        int it_done = 0;
+
+        int bad = qp.always_infeasible != 0;
+        for (int r = tid; r < qp.npar; r += BT) {
+            double v = qp.gp0[r];
+            for (int c = 0; c < nx; ++c) v += qp.Ep[r * nx + c] * xin[c];
+            if (v < -1e-9 * (1.0 + fabs(qp.gp0[r]))) bad = 1;
+        }
+        bad = __syncthreads_or(bad);
+
+        double qn_l = 1.0;
+        if (tid < NVP) {
+            double v = 0.0;
+            if (tid < nv)
+                for (int c = 0; c < nx; ++c) v += qp.F1s[tid * nx + c] * xin[c] + qp.F2s[tid * nx + c] * xin[16 + c];
+            qv[tid] = v;
+            qn_l = fmax(qn_l, fabs(v));
+        }
+        double hn_l = 1.0;
+        for (int r = tid; r < ncp; r += BT) {
+            double v = bq.g0[r];
+            for (int c = 0; c < nx; ++c) v += bq.Es[static_cast<size_t>(r) * nx + c] * xin[c];
+            h_[r] = v;
+            if (r < nc) hn_l = fmax(hn_l, fabs(v));
+        }
+        __syncthreads();
+        // z = -Hinv q (Hinv symmetric: column read = coalesced)
+        if (tid < NVP) {
+            double v = 0.0;
+            #pragma unroll 4
+            for (int j = 0; j < NVP; ++j) v -= qp.Hinv[j * NVP + tid] * qv[j];
+            zv[tid] = v;
+        }
+        __syncthreads();
+        double smin_l = INFINITY;
+        for (int r = tid; r < ncp; r += BT) {
+            const double gz = row_dot(Gcm, ncp, nv, r, zv);
+            const double sv = h_[r] - gz;
+            gz_[r] = gz;
+            s_[r] = sv;
+            lam_[r] = 0.0;
+            if (r < nc) smin_l = fmin(smin_l, sv);
+        }
+        block_reduce3<OpMax, OpMax, OpMin>(qn_l, hn_l, smin_l, red, wave, lane);
+        const double qn = qn_l, hn = hn_l, smin = smin_l;
+
+        if (bad) {
+            st = TMPC_STATUS_INFEASIBLE;
+        } else if (smin >= 0.0) {
+            st = TMPC_STATUS_OPTIMAL;
+        } else {
+            // ------------------------------------------------------------ interior point
+            {
+                const double fl = 0.1 * fmax(-smin, 1.0);
+                for (int r = tid; r < ncp; r += BT) {
+                    const bool valid = r < nc;
+                    s_[r] = valid ? fmax(s_[r], fl) : 1.0;
+                    lam_[r] = valid ? 1.0 : 0.0;
+                }
+            }
+            double try_tol = qp.tol;
+            const double ncd = static_cast<double>(nc);
+            int it = 0;
+            double rdn_last = 0.0;
+            for (;;) {
+                bool want_polish = false;
+                for (; it < qp.max_iter; ++it) {
+                    it_done = it;
+                    // ---- P1: residuals and scalings per row
+                    double gap = 0.0, rpn = 0.0, lmax = 0.0;
+                    for (int r = tid; r < ncp; r += BT) {
+                        const bool valid = r < nc;
+                        const double sv = s_[r], lv = lam_[r];
+                        const double rp = gz_[r] + sv - h_[r];
+                        const double rs = valid ? fast_rcp(sv) : 0.0;
+                        const double d = lv * rs;
+                        rp_[r] = rp;
+                        d_[r] = d;
+                        v1_[r] = d * rp;
+                        gap += sv * lv;
+                        rpn = fmax(rpn, fabs(rp));
+                        lmax = fmax(lmax, lv);
+                    }
+                    block_reduce3<OpSum, OpMax, OpMax>(gap, rpn, lmax, red, wave, lane);
+                    const double mu = gap / ncd;
+                    // ---- P2: cost gradient, G'lam, G'(d.rp)
+                    if (tid < NVP) {
+                        double v = qv[tid];
+                        #pragma unroll 4
+            for (int j = 0; j < NVP; ++j) v += qp.Hs[j * NVP + tid] * zv[j];
+                        cgv[tid] = v;
+                    }
+                    gt_products<T>(Grm, nc, lam_, v1_, parts, glv, tv, tid);
+                    double rdn = 0.0, obj = 0.0, gln = 0.0;
+                    if (tid < NVP) {
+                        const double cgj = cgv[tid], qj = qv[tid];
+                        rdn = fabs(cgj + glv[tid]);
+                        obj = zv[tid] * (0.5 * (cgj - qj) + qj);
+                        gln = fabs(glv[tid]);
+                        rhsv[tid] = -cgj - tv[tid];
+                    }
+                    block_reduce3<OpMax, OpSum, OpMax>(rdn, obj, gln, red, wave, lane);
+                    if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
+                    const double objs = fmax(fabs(obj), 1.0);
+                    const bool try_polish = (rdn <= 1e3 * try_tol * qn) && (rpn <= try_tol * hn) && (gap <= try_tol * objs);
+                    if (try_polish) { want_polish = true; rdn_last = rdn; break; }
+                    if (gap <= 1e-15 * objs) { st = TMPC_STATUS_MAX_ITER; break; }
+                    if (lmax > 1e10) {
+                        double hl = 0.0;
+                        for (int r = tid; r < nc; r += BT) hl += h_[r] * lam_[r];
+                        hl = block_reduce1<OpSum>(hl, red, wave, lane);
+                        if (hl < 0.0 && gln <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
+                    }
+                    // ---- P3 + P4: M = Hs + G'DG (MFMA), Cholesky, predictor solve
+                    double shift = 0.0;
+                    bool spd = false;
+                    for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
+                        __syncthreads();
+                        for (int idx = tid; idx < NVP * NVP; idx += BT) {
+                            const int i = idx / NVP, j = idx - i * NVP;
+                            big[i * LDM + j] = qp.Hs[idx] + (i == j ? shift : 0.0);
+                        }
+                        __syncthreads();
+                        gdg_all<T>(Grm, d_, nsteps, big, wave, lane);
+                        spd = block_chol(big, LDM, nv, dinv, tid);
+                        if (!spd) {
+                            double trc = 0.0;
+                            for (int i = 0; i < nv; ++i) trc += qp.Hs[i * NVP + i];
+                            shift = 1e-13 * (trc + lmax);
+                        }
+                    }
+                    if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
+                    if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, rhsv, dzav, lane, NVP);
+                    __syncthreads();
+                    // ---- P5: affine step statistics, corrector terms per row
+                    double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
+                    for (int r = tid; r < ncp; r += BT) {
+                        const bool valid = r < nc;
+                        const double gd = row_dot(Gcm, ncp, nv, r, dzav);
+                        const double sv = s_[r], lv = lam_[r], rp = rp_[r], d = d_[r];
+                        const double rs = valid ? fast_rcp(sv) : 0.0;
+                        const double dsa = valid ? (-rp - gd) : 0.0;
+                        const double dla = valid ? (-lv - d * dsa) : 0.0;
+                        const double rl = valid ? fast_rcp(lv) : 0.0;
+                        rho_aff = fmax(rho_aff, fmax(-dsa * rs, -dla * rl));
+                        const double w = dsa * dla;
+                        sb1 += sv * dla + lv * dsa;
+                        sb2 += w;
+                        w_[r] = w;
+                        c1_[r] = w * rs;
+                        rs_[r] = rs;
+                    }
+                    block_reduce3<OpMax, OpSum, OpSum>(rho_aff, sb1, sb2, red, wave, lane);
+                    const double aaff = rho_aff > 1.0 ? 1.0 / rho_aff : 1.0;
+                    const double mu_aff = (gap + aaff * sb1 + aaff * aaff * sb2) / ncd;
+                    double sigma = mu_aff / mu;
+                    sigma = fmin(sigma * sigma * sigma, 1.0);
+                    const double smu = sigma * mu;
+                    // ---- P6: corrector right-hand side and solve
+                    gt_products<T>(Grm, nc, c1_, rs_, parts, tv, uv, tid);
+                    if (tid < NVP) cgv[tid] = rhsv[tid] + tv[tid] - smu * uv[tid];
+                    __syncthreads();
+                    if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, cgv, dzv, lane, NVP);
+                    __syncthreads();
+                    // ---- P7: final direction per row, step length
+                    double om = (1.0 - aaff) * (1.0 - aaff);
+                    om = fmin(fmax(om, 1e-4), 1e-2);
+                    const double tau = 1.0 - om;
+                    double rho = 0.0;
+                    for (int r = tid; r < ncp; r += BT) {
+                        const bool valid = r < nc;
+                        const double gd = row_dot(Gcm, ncp, nv, r, dzv);
+                        const double sv = s_[r], lv = lam_[r], rp = rp_[r], rs = rs_[r];
+                        const double dsk = valid ? (-rp - gd) : 0.0;
+                        const double rc = sv * lv + w_[r] - smu;
+                        const double dlk = valid ? (-(rc + lv * dsk) * rs) : 0.0;
+                        const double rl = valid ? fast_rcp(lv) : 0.0;
+                        rho = fmax(rho, fmax(-dsk * rs, -dlk * rl));
+                        gdz_[r] = gd;
+                        ds_[r] = dsk;
+                        dl_[r] = dlk;
+                    }
+                    rho = block_reduce1<OpMax>(rho, red, wave, lane);
+                    const double alpha = rho > tau ? tau / rho : 1.0;
+                    // ---- P8: update
+                    for (int r = tid; r < ncp; r += BT) {
+                        s_[r] += alpha * ds_[r];
+                        lam_[r] += alpha * dl_[r];
+                        gz_[r] += alpha * gdz_[r];
+                    }
+                    if (tid < NVP) zv[tid] += alpha * dzv[tid];
+                    __syncthreads();
+                    it_done = it + 1;
+                }
+                if (!want_polish) break;
+                // ------------------------------------------------ active-set refinement
+                bool ok = false;
+                {
+                    double *S = big;
+                    for (int r = tid; r < ncp; r += BT) {
+                        const double lv = lam_[r];
+                        inW_[r] = (r < nc && lv > s_[r]) ? 1 : 0;
+                        yall_[r] = lv;
+                    }
+                    if (tid < NVP) zpv[tid] = zv[tid];
+                    for (int round = 0; round < 6 && !ok; ++round) {
+                        __syncthreads();
+                        if (wave == 0) {
+                            int m0 = 0;
+                            for (int r0 = 0; r0 < ncp; r0 += WAVE) {
+                                const int r = r0 + lane;
+                                const bool in = inW_[r] != 0;
+                                const unsigned long long bal = __ballot(in);
+                                const int pos = m0 + __popcll(bal & ((1ull << lane) - 1ull));
+                                if (in && pos < WCAP) { Widx[pos] = r; yv[pos] = yall_[r]; }
+                                m0 += __popcll(bal);
+                            }
+                            if (lane == 0) ibc[0] = m0;
+                        }
+                        __syncthreads();
+                        const int m = ibc[0];
+                        if (m > WCAP) break;
+                        if (m == 0) {
+                            if (tid < NVP) {
+                                double v = 0.0;
+                                #pragma unroll 4
+            for (int j = 0; j < NVP; ++j) v -= qp.Hinv[j * NVP + tid] * qv[j];
+                                zpv[tid] = v;
+                            }
+                            __syncthreads();
+                        } else {
+                            // S = G_W Hinv G_W' (lower triangle): rows of G Hinv (precomputed) . rows of G
+                            for (int idx = tid; idx < m * m; idx += BT) {
+                                const int a = idx / m, c2 = idx - a * m;
+                                if (c2 > a) continue;
+                                const double *ga = GHrm + static_cast<size_t>(Widx[a]) * NVP;
+                                const double *gc = Grm + static_cast<size_t>(Widx[c2]) * NVP;
+                                double v0 = 0.0, v1 = 0.0;
+                                #pragma unroll 4
+            for (int j = 0; j + 1 < NVP; j += 2) { v0 = fma(ga[j], gc[j], v0); v1 = fma(ga[j + 1], gc[j + 1], v1); }
+                                S[a * LDSS + c2] = v0 + v1;
+                            }
+                            __syncthreads();
+                            double dmax = (tid < m) ? S[tid * LDSS + tid] : 0.0;
+                            dmax = block_reduce1<OpMax>(dmax, red, wave, lane);
+                            if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
+                            if (!block_chol(S, LDSS, m, dinv, tid)) break;
+                            for (int stp = 0; stp < 4; ++stp) {
+                                // r1 = Hs zp + q + G_W' y
+                                if (tid < NVP) {
+                                    double v = qv[tid];
+                                    #pragma unroll 4
+            for (int j = 0; j < NVP; ++j) v += qp.Hs[j * NVP + tid] * zpv[j];
+                                    for (int k = 0; k < m; ++k) v += Grm[static_cast<size_t>(Widx[k]) * NVP + tid] * yv[k];
+                                    tv[tid] = v;
+                                }
+                                __syncthreads();
+                                // t1 = Hinv r1
+                                if (tid < NVP) {
+                                    double v = 0.0;
+                                    #pragma unroll 4
+            for (int j = 0; j < NVP; ++j) v += qp.Hinv[j * NVP + tid] * tv[j];
+                                    uv[tid] = v;
+                                }
+                                __syncthreads();
+                                // dy rhs: (G_W zp - h_W) - G_W t1
+                                if (tid < m) {
+                                    const int r = Widx[tid];
+                                    const double *g = Grm + static_cast<size_t>(r) * NVP;
+                                    double gz = 0.0, gt = 0.0;
+                                    #pragma unroll 4
+            for (int j = 0; j < NVP; ++j) { gz = fma(g[j], zpv[j], gz); gt = fma(g[j], uv[j], gt); }
+                                    dyv[tid] = gz - h_[r] - gt;
+                                }
+                                __syncthreads();
+                                if (wave == 0) wave_llt_solve(S, LDSS, m, dinv, dyv, dyv, lane);
+                                __syncthreads();
+                                // zp -= t1 + Hinv G_W' dy ; y += dy
+                                if (tid < NVP) {
+                                    double v = uv[tid];
+                                    for (int k = 0; k < m; ++k) v += GHrm[static_cast<size_t>(Widx[k]) * NVP + tid] * dyv[k];
+                                    zpv[tid] -= v;
+                                }
+                                if (tid < m) yv[tid] += dyv[tid];
+                                __syncthreads();
+                            }
+                        }
+                        // ---- verify: primal feasibility on all rows, sign of y on W
+                        double ymax = (tid < m) ? fabs(yv[tid]) : 1.0;
+                        ymax = fmax(ymax, 1.0);
+                        ymax = block_reduce1<OpMax>(ymax, red, wave, lane);
+                        if (tid < m) yall_[Widx[tid]] = yv[tid];
+                        __syncthreads();
+                        double nviol = 0.0, nneg = 0.0, nloose = 0.0;
+                        for (int r = tid; r < ncp; r += BT) {
+                            const bool valid = r < nc;
+                            const double hk = h_[r];
+                            const double rr = row_dot(Gcm, ncp, nv, r, zpv) - hk;
+                            rr_[r] = rr;
+                            const bool in = inW_[r] != 0;
+                            const double hi = fmax(fabs(hk), 1.0);
+                            const bool viol = valid && !in && rr > 1e-12 * hi;
+                            const bool loose = in && fabs(rr) > 1e-11 * hi;
+                            const bool neg = in && yall_[r] < -1e-10 * ymax;
+                            nviol += viol ? 1.0 : 0.0;
+                            nneg += neg ? 1.0 : 0.0;
+                            nloose += loose ? 1.0 : 0.0;
+                            if (neg) { inW_[r] = 0; yall_[r] = 0.0; }
+                            if (viol) { inW_[r] = 1; yall_[r] = 0.0; }
+                        }
+                        block_reduce3<OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
+                        if (nloose != 0.0) break;
+                        if (nviol == 0.0 && nneg == 0.0) {
+                            ok = true;
+                            if (tid < NVP) zv[tid] = zpv[tid];
+                            for (int r = tid; r < ncp; r += BT) {
+                                const double rr = rr_[r];
+                                lam_[r] = inW_[r] ? fmax(yall_[r], 0.0) : 0.0;
+                                s_[r] = rr < 0.0 ? -rr : 0.0;
+                                gz_[r] = rr + h_[r];
+                            }
+                            __syncthreads();
+                        }
+                    }
+                }
+                if (ok) { st = TMPC_STATUS_OPTIMAL; break; }
+                if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
+                try_tol *= 1e-2;
+            }
+            if (st == TMPC_STATUS_MAX_ITER) {
+                // iteration cap: if the iterate still violates the constraints, call it infeasible
+                double viol = 0.0;
+                for (int r = tid; r < nc; r += BT) viol = fmax(viol, gz_[r] - h_[r]);
+                viol = block_reduce1<OpMax>(viol, red, wave, lane);
+                if (viol > 1e-6 * hn) st = TMPC_STATUS_INFEASIBLE;
+            }
+        }
+
+        // ---------------------------------------------------------------- outputs
+        const bool good = st < TMPC_STATUS_INFEASIBLE;
+        const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+        __syncthreads();
+        if (tid < NVP) tv[tid] = (tid < nv) ? qp.Dv[tid] * zv[tid] : 0.0;     // unscaled z
+        __syncthreads();
+        for (int i = tid; i < N * nu; i += BT) u_nom[b * N * nu + i] = good ? tv[i] : nanv;
+        if (tid < nx + nu && xu_ss) {
+            double v = 0.0;
+            for (int j = 0; j < qp.nth; ++j) v += qp.Mth[tid * qp.nth + j] * tv[qp.off_theta + j];
+            xu_ss[b * (nx + nu) + tid] = good ? v : nanv;
+        }
+        if (tid < nx) {
+            const double x0 = (qp.off_x0 >= 0) ? tv[qp.off_x0 + tid] : xin[tid];
+            if (x_nom0) x_nom0[b * nx + tid] = good ? x0 : nanv;
+            uv[tid] = x0;
+        }
+        if (x_nom) {
+            __syncthreads();
+            if (tid < nx) x_nom[b * (N + 1) * nx + tid] = good ? uv[tid] : nanv;
+            for (int i = 0; i < N; ++i) {
+                double v = 0.0;
+                if (tid < nx) {
+                    for (int j = 0; j < nx; ++j) v += qp.A[tid * nx + j] * uv[j];
+                    for (int j = 0; j < nu; ++j) v += qp.B[tid * nu + j] * tv[i * nu + j];
+                }
+                __syncthreads();
+                if (tid < nx) { uv[tid] = v; x_nom[b * (N + 1) * nx + (i + 1) * nx + tid] = good ? v : nanv; }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) { status[b] = st; iters[b] = it_done; }
+    }
+}
+
+template <int T>
+hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int ws_blocks, int variant_id, int64_t B,
+                          const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
+                          double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
+    constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
+    static_assert(lds <= 160 * 1024, "block shape does not fit the 160 KiB LDS of a CU");
+    static bool attr_set[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_block_kernel<T>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+    }
+    int64_t blocks = B < ws_blocks ? B : ws_blocks;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL((solve_block_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(BT), lds, stream, qp, bq, ws, variant_id, B,
+                       x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
+    return hipGetLastError();
+}
+
+template <int T>
+int block_occupancy_t() {
+    constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              static_cast<int>(lds));
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, solve_block_kernel<T>, BT, lds) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
+}  // namespace
+
+int block_tiles(int nv) {
+    if (nv <= 16) return 1;
+    if (nv <= 32) return 2;
+    if (nv <= 64) return 4;
+    if (nv <= 128) return 8;
+    return 0;
+}
+
+int block_workspace_rows() { return WS_COUNT; }
+
+size_t block_lds_bytes(int tiles) {
+    switch (tiles) {
+        case 1: return sizeof(double) * BShape<1>::TOTAL;
+        case 2: return sizeof(double) * BShape<2>::TOTAL;
+        case 4: return sizeof(double) * BShape<4>::TOTAL;
+        case 8: return sizeof(double) * BShape<8>::TOTAL;
+    }
+    return 0;
+}
+
+int block_occupancy(int tiles) {
+    switch (tiles) {
+        case 1: return block_occupancy_t<1>();
+        case 2: return block_occupancy_t<2>();
+        case 4: return block_occupancy_t<4>();
+        case 8: return block_occupancy_t<8>();
+    }
+    return 1;
+}
+
+hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
+                        const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
+    switch (tiles) {
+        case 1: return launch_block_t<1>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 2: return launch_block_t<2>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 4: return launch_block_t<4>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 8: return launch_block_t<8>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace tmpc

@@ -118,7 +118,10 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     const bool received = variant == 1;
     if (received && !p.extended) return "variant 1 requested but problem is not extended";
     const bool fixed = !received && p.fixed_x0;
-    const bool aux = received && p.literal_terminal_row;
+    // packet-received problem, literal terminal row (:293): auxiliaries eliminated when the caller supplies
+    // the projection (HTP, hTP), kept with a vanishing weight otherwise (include/tmpc.h)
+    const bool projected = received && p.literal_terminal_row && p.rTP > 0 && p.HTP && p.hTP;
+    const bool aux = received && p.literal_terminal_row && !projected;
     const int rz = received ? p.rZW : (fixed ? 0 : p.rZ);
     const double *HZp = received ? p.HZW : p.HZ, *hZp = received ? p.hZW : p.hZ;
     if (!p.A || !p.B || !p.Q || !p.R || !p.P || !p.T) return "A, B, Q, R, P, T must be given";
@@ -225,7 +228,15 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         add_rows(Hx, p.hx, x[i]);        // :139
         add_rows(Hu, p.hu, u[i]);        // :140
     }
-    {
+    if (projected) {
+        // HTP [x_bar; u_bar] <= hTP: line :293 after eliminating the free (x_N', u_bar')
+        Aff st(nx + nu, nv, nx);
+        for (int j = 0; j < nv; ++j) {
+            for (int i = 0; i < nx; ++i) st.L(i, j) = xbar.L(i, j);
+            for (int i = 0; i < nu; ++i) st.L(nx + i, j) = ubar.L(i, j);
+        }
+        add_rows(from_ptr(p.HTP, p.rTP, nx + nu), p.hTP, st);
+    } else {
         // HT [x_T; x_bar; u_T] <= hT   (:149; for variant 1 literally :293)
         const Aff xT = aux ? selector(nx, c.off_aux) : x[N];
         const Aff uT = aux ? selector(nu, c.off_aux + nx) : ubar;

@@ -53,6 +53,16 @@ struct WarmStart {
     int ncp;
 };
 
+// Block path (tmpc_block.hip): all rows dense, row order of Condensed::Gs, nv padded to 16 * tiles
+struct BlockQP {
+    int ncp;              // padded row count (multiple of 64)
+    const double *Grm;    // [ncp][NVP]  scaled G, row-major, zero padded (MFMA operands, G'v passes)
+    const double *Gcm;    // [NVP][ncp]  the same, column-major (thread-per-row products)
+    const double *GHrm;   // [ncp][NVP]  G * Hs^-1, row-major (refinement: S = G_W Hs^-1 G_W')
+    const double *g0;     // [ncp]       right-hand side offsets (padding rows: 1)
+    const double *Es;     // [ncp][nx]   right-hand side dependence on x_k
+};
+
 struct KernelShape {
     int nvp = 0, rd = 0, kcp = 0, rc = 0;
 };
@@ -65,6 +75,15 @@ size_t lds_bytes(const KernelShape &shape);
 hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, const WarmStart &warm, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream);
+
+// Block path: tiles = NVP / 16 in {1, 2, 4, 8} (0: nv > 128, unsupported); workspace = blocks * rows * ncp doubles
+int block_tiles(int nv);
+int block_workspace_rows();
+size_t block_lds_bytes(int tiles);
+int block_occupancy(int tiles);
+hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
+                        const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream);
 
 size_t stream_lds_bytes(int nvp, int ncp, int nx);
 bool stream_supported(int nvp, int ncp, int nx);

@@ -18,10 +18,13 @@ from LinearMPCOverNetworks.TubeTrackingMPC import ExtendedTubeTrackingMPC, TubeT
 
 _SETS = {"cartpole": "cartpole_sets.npz",
          "double_integrator": "double_integrator_rakovic_sets.npz",
-         "double_integrator_darup": "double_integrator_darup_sets.npz"}
+         "double_integrator_darup": "double_integrator_darup_sets.npz",
+         "synthetic": "synthetic_sets.npz"}
 
 
 def workload(name: str):
+    if name == "synthetic":
+        return workloads.synthetic()
     return workloads.cartpole() if name == "cartpole" else workloads.double_integrator()
 
 

@@ -41,3 +41,4 @@ if __name__ == "__main__":
     make("double_integrator_rakovic", workloads.double_integrator(), 0)
     make("double_integrator_darup", workloads.double_integrator(), 1)
     make("cartpole", workloads.cartpole(), 1)
+    make("synthetic", workloads.synthetic(), 1)

@@ -19,16 +19,16 @@ def test_library_exports_every_declared_symbol(hip_lib):
     declared = set(re.findall(r"\b(tmpc_[a-z_]+)\s*\(", hdr))
     assert {"tmpc_create", "tmpc_destroy", "tmpc_solve_batch", "tmpc_solve_batch_device", "tmpc_synchronize", "tmpc_set_stream_min_batch",
             "tmpc_last_kernel_ms", "tmpc_kernel_ms_total", "tmpc_get_dims", "tmpc_get_condensed", "tmpc_last_error",
-            "tmpc_abi_version"} <= declared
+            "tmpc_abi_version", "tmpc_set_kernel_path", "tmpc_get_kernel_path"} <= declared
     L = hip_lib.lib()
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/tmpc.h but not exported"
-    assert L.tmpc_abi_version() == 1
+    assert L.tmpc_abi_version() == 2
 
 
 def test_struct_layout_matches_header(hip_lib):
-    """ctypes mirror == C struct: 12 int32, one double, 18 pointers."""
-    assert C.sizeof(hip_lib.TmpcProblem) == 12 * 4 + 8 + 18 * 8
+    """ctypes mirror == C struct: 12 int32, one double, 20 pointers, one int32 (+ tail padding)."""
+    assert C.sizeof(hip_lib.TmpcProblem) == 12 * 4 + 8 + 20 * 8 + 8
 
 
 def test_argument_errors_are_reported_not_thrown(hip_lib):

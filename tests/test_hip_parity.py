@@ -28,7 +28,7 @@ def cartpole(hip_lib, oracle_lib):
 
 def test_native_library_is_the_one_in_tree(hip_lib):
     assert os.path.samefile(hip_lib.LIB_PATH, os.path.join(common.PKG, "lib", "libtmpc_hip.so"))
-    assert hip_lib.lib().tmpc_abi_version() == 1
+    assert hip_lib.lib().tmpc_abi_version() == 2
 
 
 def test_golden_fixture_cartpole_N10(cartpole, hip_lib):
@@ -236,3 +236,78 @@ def test_config1_double_integrator_closed_loop(hip_lib, oracle_lib, N):
         x = A @ x + B @ u + rng.uniform(-0.1, 0.1, 2)
     assert worst < ATOL_U
     assert abs(x[0] - 4.0) < 0.5
+
+
+def test_block_kernel_matches_fixture_and_wave_kernel(cartpole, hip_lib):
+    """The workgroup-per-QP kernel (csrc/tmpc_block.hip: MFMA G'DG, LDS Cholesky), forced onto the bench
+    problem: same minimisers as the fixture, same statuses and iteration counts as the wave kernel on the
+    edge cases."""
+    mpc, _, _ = cartpole
+    gold = np.load(os.path.join(common.GOLDEN, "cartpole_N10_oracle.npz"))
+    X = np.r_[S[:, :4], [[0.0, 0.0, 0.2, 0.0], [0.5, 0.0, 0.0, 0.0]]]      # + infeasible, + unconstrained
+    R = np.r_[S[:, 4:], [[0.5, 0, 0, 0.0], [0.5, 0, 0, 0.0]]]
+    assert mpc.get_kernel_path() == "wave"
+    base = mpc._solve(X, R)
+    mpc.set_kernel_path("block")
+    try:
+        assert mpc.get_kernel_path() == "block"
+        out = mpc._solve(X, R)
+    finally:
+        mpc.set_kernel_path("auto")
+    assert np.array_equal(out["status"], base["status"]) and list(out["status"][-2:]) == [2, 0]
+    assert out["iters"][-1] == 0 and np.all(np.isnan(out["u_nom"][-2]))
+    np.testing.assert_allclose(out["u_nom"][:600], gold["u_nom"], atol=ATOL_U, rtol=0)
+    np.testing.assert_allclose(out["xu_ss"][:600], gold["xu_ss"], atol=ATOL_SS, rtol=0)
+    np.testing.assert_allclose(out["x_nom"][:600], gold["x_nom"], atol=1e-8, rtol=0)
+    assert np.abs(out["iters"][:600].astype(int) - base["iters"][:600]).max() <= 1
+
+
+@pytest.mark.parametrize("N", [10, 20])
+def test_extended_controller_both_problems(hip_lib, oracle_lib, N):
+    """BASELINE config 3: ExtendedTubeTrackingMPC (TubeTrackingMPC.py:249-369), gamma_t per instance.  The
+    packet-received problem (Z (-) W on x_0, auxiliaries of :293 eliminated) goes through the block kernel."""
+    mpc, _ = common.make_mpc("cartpole", N, True, extended=True, create=True)
+    nv1, nc1, _ = hip_lib.get_dims(mpc._handle, 1)
+    assert nv1 == N + 1 + 4 and nc1 > 900 and mpc.get_kernel_path(1) == "block"
+    SX = common.harvest_states("cartpole", N, True, [[0.5], [-0.4, 0.3], [0.2, -0.5, 0.1]], 40, seed=4, disturb=True, extended=True)
+    gam = np.random.default_rng(1).integers(0, 2, len(SX)).astype(np.uint8)
+    ref = Oracle(mpc._problem_dict()).solve(SX[:, :4], SX[:, 4:], gam)
+    x_nom, u_nom, x_ss, u_ss = mpc.solve_optimization_problem(SX[:, :4], SX[:, 4:], gam)
+    assert np.array_equal(mpc.last_status, ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() > 60 and (ok & (gam == 1)).sum() > 20
+    np.testing.assert_allclose(u_nom[ok], ref["u_nom"][ok], atol=1e-7, rtol=0)
+    np.testing.assert_allclose(u_nom[ok, 0], ref["u_nom"][ok, 0], atol=ATOL_U, rtol=0)          # u*_0
+    np.testing.assert_allclose(x_nom[ok, 0], ref["x_nom0"][ok], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(np.c_[x_ss, u_ss][ok], ref["xu_ss"][ok], atol=ATOL_SS, rtol=0)
+    # gamma = 0 instances keep x_0 = x_k, gamma = 1 instances move it inside x_k (+) (Z (-) W)  (:278)
+    g0, g1 = ok & (gam == 0), ok & (gam == 1)
+    np.testing.assert_allclose(x_nom[g0, 0], SX[g0, :4], atol=1e-12)
+    assert np.all(mpc._ZmW.contains((SX[g1, :4] - x_nom[g1, 0]).T, 1e-9))
+    # the reference's single-instance API (:351-369): packet dict + x_nom_0
+    i = int(np.flatnonzero(g1)[0])
+    packet, x0 = mpc.determine_packet(SX[i, :4], SX[i, 4:], 7, gamma_t=1)
+    assert packet["U_t"].shape == (1, N + 1) and packet["q_t"] == 7
+    np.testing.assert_allclose(x0, ref["x_nom0"][i], atol=1e-8)
+
+
+def test_config5_synthetic_n12_m4_N30(hip_lib, oracle_lib):
+    """BASELINE config 5: random stable (A, B), n = 12, m = 4, N = 30 -> nv = 124, ~1.2e3 rows; block kernel,
+    G'DG on the FP64 matrix cores."""
+    mpc, _ = common.make_mpc("synthetic", 30, True, create=True)
+    nv, nc, npar = hip_lib.get_dims(mpc._handle)
+    assert nv == 124 and npar == 24 and mpc.get_kernel_path() == "block"
+    rng = np.random.default_rng(0)
+    B = 192
+    X = rng.uniform(-0.5, 0.5, (B, 12)) * mpc._Xc.b[:12]
+    X[:64] *= 1.9                                         # near the boundary of Xc: many active rows
+    R = np.zeros((B, 12))
+    R[:, 0] = rng.uniform(-2, 2, B)
+    ref = Oracle(mpc._problem_dict()).solve(X, R)
+    out = mpc._solve(X, R)
+    assert np.array_equal(out["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() > 100 and ref["iters"][ok].max() >= 8
+    np.testing.assert_allclose(out["u_nom"][ok], ref["u_nom"][ok], atol=ATOL_U, rtol=0)
+    np.testing.assert_allclose(out["xu_ss"][ok], ref["xu_ss"][ok], atol=ATOL_SS, rtol=0)
+    np.testing.assert_allclose(out["x_nom"][ok], ref["x_nom"][ok], atol=1e-8, rtol=0)

@@ -125,3 +125,41 @@ def test_control_helpers():
     np.testing.assert_allclose(Acl @ P @ Acl.T - P + Ql, 0, atol=1e-5 * np.abs(P).max())
     Ad, Bd = c2d(np.zeros((1, 1)), np.ones((1, 1)), 0.5)
     np.testing.assert_allclose([Ad[0, 0], Bd[0, 0]], [1.0, 0.5])
+
+
+def test_projection_by_convex_hull_method():
+    """project_polytope against the projected vertices of a rotated cube (exact V-representation)."""
+    rng = np.random.default_rng(1)
+    Q, _ = np.linalg.qr(rng.standard_normal((4, 4)))
+    cube = Polytope(np.r_[np.eye(4), -np.eye(4)] @ Q.T, np.ones(8))
+    for k in (1, 2, 3):
+        E = rng.standard_normal((k, 4))
+        Pk = up.project_polytope(cube, E)
+        V = up.extreme(cube) @ E.T
+        assert np.max(Pk.A @ V.T - Pk.b[:, None]) < 1e-9              # contains every projected vertex
+        Hk = up.determine_convex_hull(V)
+        assert Pk.A.shape[0] == Hk.A.shape[0]
+        assert is_subset(Pk, Hk, 1e-8) and is_subset(Hk, Pk, 1e-8)
+
+
+def test_terminal_auxiliaries_elimination_is_exact():
+    """HTP [x_bar; u_bar] <= hTP  <=>  some (x_aux, u_aux) satisfies the literal rows of TubeTrackingMPC.py:293,
+    for steady states (x_bar, u_bar) on either side of the boundary."""
+    from scipy.optimize import linprog
+    import os
+    sets = dict(np.load(os.path.join(common.GOLDEN, "cartpole_sets.npz")))
+    w = workloads.cartpole()
+    Xf = Polytope(sets["Xf_A"], sets["Xf_b"])
+    PT = up.eliminate_terminal_auxiliaries(Xf, w["A"], w["B"])
+    assert PT.A.shape == (2, 5)                                        # nu = 1: an interval of steady states
+    Nss = up.steady_state_basis(w["A"], w["B"])
+    assert np.max(np.abs(np.c_[w["A"] - np.eye(4), w["B"]] @ Nss)) < 1e-12
+    # boundary values of phi along the basis
+    hi = min(b / (a @ Nss[:, 0]) for a, b in zip(PT.A, PT.b) if a @ Nss[:, 0] > 0)
+    lo = max(b / (a @ Nss[:, 0]) for a, b in zip(PT.A, PT.b) if a @ Nss[:, 0] < 0)
+    HT, hT = Xf.A, Xf.b
+    for phi, inside in ((0.0, True), (hi * (1 - 1e-6), True), (lo * (1 - 1e-6), True), (hi * (1 + 1e-4), False), (lo * (1 + 1e-4), False)):
+        xu = Nss[:, 0] * phi
+        res = linprog(np.zeros(5), A_ub=np.c_[HT[:, :4], HT[:, 8:]], b_ub=hT - HT[:, 4:8] @ xu[:4], bounds=(None, None), method="highs")
+        assert (res.status == 0) == inside
+        assert bool(np.all(PT.A @ xu <= PT.b + 1e-12)) == inside

@@ -133,10 +133,12 @@ def test_double_integrator_free_initial_state_vs_scipy(oracle_lib):
 
 
 def test_extended_variant_builds_and_solves(oracle_lib):
-    """Packet-received problem (TubeTrackingMPC.py:253-299) incl. the literal terminal row (:293)."""
+    """Packet-received problem (TubeTrackingMPC.py:253-299) with the literal terminal row (:293) kept on free
+    auxiliaries (the fall-back when no projection is supplied)."""
     mpc, w = common.make_mpc("double_integrator", 5, True, extended=True)
+    mpc._eliminate_auxiliaries = False
     p = mpc._problem_dict()
-    assert p["extended"] == 1
+    assert p["extended"] == 1 and "HTP" not in p
     orc = Oracle(p)
     nv0, nc0, _ = orc.dims(0)
     nv1, nc1, _ = orc.dims(1)
@@ -156,3 +158,36 @@ def test_extended_variant_builds_and_solves(oracle_lib):
     rows = np.flatnonzero(np.abs(qp["G"][:, L.oxa:]).sum(axis=1) == 0)
     assert np.max(qp["G"][rows] @ v - qp["h"][rows]) < 1e-9
     assert np.max(np.abs(qp["A"] @ v - qp["b"])) < 1e-9
+
+
+def test_extended_variant_with_auxiliaries_eliminated(oracle_lib):
+    """Default form of the packet-received problem: line :293's free auxiliaries projected out at set-up
+    (include/tmpc.h: HTP).  Same minimiser as the literal form, certified on the un-condensed QP."""
+    from scipy.optimize import linprog
+    mpc, w = common.make_mpc("double_integrator", 5, True, extended=True)
+    p = mpc._problem_dict()
+    assert p["HTP"].shape[1] == 3
+    orc = Oracle(p)
+    assert orc.dims(1)[0] == 5 + 1 + 2            # u, theta, x_0 -- no auxiliaries
+    mpc2, _ = common.make_mpc("double_integrator", 5, True, extended=True)
+    mpc2._eliminate_auxiliaries = False
+    p_lit = mpc2._problem_dict()
+    orc_lit = Oracle(p_lit)
+    rng = np.random.default_rng(3)
+    X = rng.uniform(-1.5, 1.5, (24, 2))
+    R = np.c_[rng.uniform(-6, 6, 24), np.zeros(24)]
+    one = np.ones(24, dtype=np.uint8)
+    a, b = orc.solve(X, R, one), orc_lit.solve(X, R, one)
+    ok = (a["status"] == 0) & (b["status"] == 0)
+    assert ok.sum() >= 12 and np.array_equal(a["status"] >= 2, b["status"] >= 2)
+    np.testing.assert_allclose(a["u_nom"][ok], b["u_nom"][ok], atol=2e-5, rtol=0)     # the literal form is only this accurate
+    HT, hT = p["HT"], p["hT"]
+    for i in np.flatnonzero(ok)[:8]:
+        qp = qp_sparse.build_sparse_qp(p, X[i], R[i], 1)
+        v = qp_sparse.pack(qp, a["x_nom"][i], a["u_nom"][i], a["x_ss"][i], a["u_ss"][i])
+        c = qp_sparse.kkt_certificate(qp, v)
+        assert c["r_eq"] < 1e-9 and c["r_ineq"] < 1e-9 and c["r_stat"] < 1e-8 and c["min_lam"] >= 0, c
+        # the literal rows are satisfiable for this x_bar: an auxiliary pair exists (LP feasibility)
+        res = linprog(np.zeros(3), A_ub=np.c_[HT[:, :2], HT[:, 4:]], b_ub=hT - HT[:, 2:4] @ a["x_ss"][i] + 1e-9,
+                      bounds=(None, None), method="highs")
+        assert res.status == 0
