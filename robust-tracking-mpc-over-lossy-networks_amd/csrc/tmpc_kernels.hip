@@ -94,6 +94,11 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
+// a wave-uniform value moved to (and from then on kept in) scalar registers: FMAs take it as their
+// one SGPR operand, and the 64-lane copies of z, dz, ... stop occupying vector registers
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 struct OpSum { __device__ __forceinline__ static double f(double a, double b) { return a + b; } };
 struct OpMin { __device__ __forceinline__ static double f(double a, double b) { return fmin(a, b); } };
 struct OpMax { __device__ __forceinline__ static double f(double a, double b) { return fmax(a, b); } };
@@ -166,7 +171,7 @@ __device__ __forceinline__ bool rows_factor(double (&row)[NV], double &b, double
     for (int k = 0; k < NV; ++k) {
         const double pkk = readlane_d(row[k], k);
         ok = ok && (pkk > 0.0);
-        const double pinv = 1.0 / pkk;
+        const double pinv = fast_rcp(pkk);
         const double f = (lane > k) ? row[k] * pinv : 0.0;
 #pragma unroll
         for (int j = k + 1; j < NV; ++j) row[j] = fma(-f, readlane_d(row[j], k), row[j]);
@@ -220,15 +225,17 @@ struct WaveLds {
     static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC;
 };
 
-// c = Psi v (KC values) for a wave-uniform v, computed redundantly by every lane (broadcast LDS reads)
+// c = Psi v (KC values) for a wave-uniform v: lane a < KC forms entry a from its row of Psi, the entries are
+// then broadcast with v_readlane, so c lives in scalar registers (one dot product per wave, not one per lane)
 template <class SH>
-__device__ __forceinline__ void factor_coords(const double *Psi, const double (&v)[SH::NV], double (&c)[SH::KCA]) {
-#pragma unroll
-    for (int a = 0; a < SH::KC; ++a) {
+__device__ __forceinline__ void factor_coords(const double *Psi, const double (&v)[SH::NV], double (&c)[SH::KCA], int lane) {
+    if constexpr (SH::KC > 0) {
+        const int a_ = lane < SH::KC ? lane : 0;
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < SH::NV; ++j) t += Psi[a * SH::NV + j] * v[j];
-        c[a] = t;
+        for (int j = 0; j < SH::NV; ++j) t += Psi[a_ * SH::NV + j] * v[j];
+#pragma unroll
+        for (int a = 0; a < SH::KC; ++a) c[a] = readlane_d(t, a);
     }
 }
 
@@ -480,13 +487,13 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         double z[NV];
         double qn = 1.0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { z[j] = zv[j]; qn = fmax(qn, fabs(qv[j])); }
+        for (int j = 0; j < NV; ++j) { z[j] = uni(zv[j]); qn = fmax(qn, fabs(qv[j])); }
 
         double s[RT], lam[RT];
         double smin = INFINITY;
         {
             double cz[KCA];
-            factor_coords<SH>(Psi, z, cz);
+            factor_coords<SH>(Psi, z, cz, lane);
             // unrolled by the template recursion below
             auto init_slot = [&](auto kc_) {
                 constexpr int k = decltype(kc_)::value;
@@ -530,7 +537,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (WARM && (st1 == 0 || st1 == 1)) {
                 // pick up (z, s, lambda) where the streaming kernel left them
 #pragma unroll
-                for (int j = 0; j < NV; ++j) z[j] = warm.z[b * NV + j];
+                for (int j = 0; j < NV; ++j) z[j] = uni(warm.z[b * NV + j]);
 #pragma unroll
                 for (int k = 0; k < RT; ++k) {
                     const int gid = k < RD ? lane + k * WAVE : nd + lane + (k - RD) * WAVE;
@@ -559,9 +566,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 // ---- sweeps A: residuals, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam
                 double gap_l = 0.0, rpn_l = 0.0;
                 if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
+                double cz[KCA];                 // Psi z, shared by the three sweeps of this iteration
                 if constexpr (KC > 0) {
-                    double cz[KCA];
-                    factor_coords<SH>(Psi, z, cz);
+                    factor_coords<SH>(Psi, z, cz, lane);
                     sweep_a_factored<SH>(Hct, hw, cz, s, lam, gap_l, rpn_l, red, csums, lane, ncc);
                     // fold the factored block into the dense totals: P = W Psi now, Psi' P when the rows are loaded
                     for (int idx = lane; idx < KC * NV; idx += WAVE) {
@@ -666,10 +673,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #pragma unroll
                 for (int j = 0; j < NV; ++j) dza[j] = dz[j];
                 double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
+                double cdza[KCA];               // Psi dza, shared by sweeps B and D
                 double v2 = 0.0, v3 = 0.0;          // lane i < NV: entries i of G'(dsa.dla/s) and G'(1/s)
                 {
-                    double cz[KCA], cdz[KCA];
-                    if constexpr (KC > 0) { factor_coords<SH>(Psi, z, cz); factor_coords<SH>(Psi, dza, cdz); }
+                    if constexpr (KC > 0) factor_coords<SH>(Psi, dza, cdza, lane);
+                    const double (&cdz)[KCA] = cdza;
                     // returns (dsa*dla/s, 1/s) of the row
                     auto row_stats = [&](int k, bool valid, double gz, double gdz, double hk, double &c1, double &rsk) {
                         rsk = valid ? fast_rcp(s[k]) : 0.0;
@@ -750,8 +758,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 const double tau = 1.0 - om;
                 double rho = 0.0;
                 {
-                    double cz[KCA], cdza[KCA], cdz[KCA];
-                    if constexpr (KC > 0) { factor_coords<SH>(Psi, z, cz); factor_coords<SH>(Psi, dza, cdza); factor_coords<SH>(Psi, dz, cdz); }
+                    double cdz[KCA];
+                    if constexpr (KC > 0) factor_coords<SH>(Psi, dz, cdz, lane);
                     auto step_row = [&](auto kc_) {
                         constexpr int k = decltype(kc_)::value;
                         const bool valid = slot_valid<SH>(k, lane, nd, ncc);
@@ -778,7 +786,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #pragma unroll
                 for (int k = 0; k < RT; ++k) { s[k] += alpha * dsv[k]; lam[k] += alpha * dlv[k]; }
 #pragma unroll
-                for (int j = 0; j < NV; ++j) z[j] += alpha * dz[j];
+                for (int j = 0; j < NV; ++j) z[j] = uni(z[j] + alpha * dz[j]);
 #pragma unroll
                 for (int j = 0; j < NV; ++j) if (lane == j) zv[j] = z[j];     // z is wave-uniform
                 wave_lds_fence();
@@ -948,7 +956,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     double rr[RT];
                     {
                         double czp[KCA];
-                        if constexpr (KC > 0) factor_coords<SH>(Psi, zp, czp);
+                        if constexpr (KC > 0) factor_coords<SH>(Psi, zp, czp, lane);
                         int mm = 0;
                         auto check_slot = [&](auto kc_) {
                             constexpr int k = decltype(kc_)::value;
@@ -997,7 +1005,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 // iteration cap: if the iterate still violates the constraints, call it infeasible
                 double viol = 0.0;
                 double cz[KCA];
-                if constexpr (KC > 0) factor_coords<SH>(Psi, z, cz);
+                if constexpr (KC > 0) factor_coords<SH>(Psi, z, cz, lane);
                 auto viol_slot = [&](auto kc_) {
                     constexpr int k = decltype(kc_)::value;
                     const double gz = row_dot<SH, k>(Gt, Hct, z, cz, lane);

@@ -5,6 +5,9 @@ import numpy as np
 import common
 from LinearMPCOverNetworks import _native
 from oracle.oracle import Oracle
+if os.environ.get('TMPC_LIB'):
+    _native.LIB_PATH = os.path.abspath(os.environ['TMPC_LIB'])
+    print('using', _native.LIB_PATH)
 
 S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
 mpc, w = common.make_mpc("cartpole", 10, True, create=True)
