@@ -201,6 +201,21 @@ __device__ __forceinline__ void rows_backsub(const double (&row)[NV], double b, 
     }
 }
 
+// back substitution that leaves x_i on lane i (instead of wave-uniform copies): the caller stores it to LDS,
+// from where the row sweeps read it with broadcast loads -- no 64-lane register copies of dz
+template <int NV>
+__device__ __forceinline__ double rows_backsub_lane(const double (&row)[NV], double b, double dinv, int lane) {
+    double xl = 0.0;
+#pragma unroll
+    for (int i = NV - 1; i >= 0; --i) {
+        const double bi = b * dinv;
+        const double xi = readlane_d(bi, i);
+        xl = (lane == i) ? bi : xl;
+        b = fma(-row[i], xi, b);
+    }
+    return xl;
+}
+
 // compile-time description of one kernel instantiation
 template <int NV_, int RD_, int KC_, int RC_>
 struct Shape {
@@ -221,7 +236,7 @@ struct WaveLds {
     static constexpr int CSUMS = SH::KT + 2 * SH::KC + 8;                               // factored-block totals
     static constexpr int PMAT = SH::KCA * SH::NV;                                       // W * Psi
     static constexpr int HROW = SH::RT * WAVE;                                          // right-hand side h, [slot][lane]
-    static constexpr int VEC = 8 * SH::NV + 32;                                         // q, z, cost gradient, x_k, ref, scratch
+    static constexpr int VEC = 9 * SH::NV + 32;                                         // q, z, cost gradient, x_k, ref, scratch, dz_aff, dz, Psi-coordinates
     static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC;
 };
 
@@ -236,6 +251,18 @@ __device__ __forceinline__ void factor_coords(const double *Psi, const double (&
         for (int j = 0; j < SH::NV; ++j) t += Psi[a_ * SH::NV + j] * v[j];
 #pragma unroll
         for (int a = 0; a < SH::KC; ++a) c[a] = readlane_d(t, a);
+    }
+}
+
+// out = Psi vec for vectors kept in LDS: lane a < KC forms entry a (broadcast reads of vec)
+template <class SH>
+__device__ __forceinline__ void coords_lds(const double *Psi, const double *vec, double *out, int lane) {
+    if constexpr (SH::KC > 0) {
+        const int a_ = lane < SH::KC ? lane : 0;
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < SH::NV; ++j) t += Psi[a_ * SH::NV + j] * vec[j];
+        if (lane < SH::KC) out[lane] = t;
     }
 }
 
@@ -267,8 +294,9 @@ __device__ __forceinline__ bool slot_valid(int k, int lane, int nd, int ncc) {
 // the gap and |r_p|_inf.  Nothing per-row is kept besides (s, lam): r_p and 1/s are recomputed by
 // the later sweeps, which is cheaper than carrying them through the register file.
 template <class SH, int J0, int J1, bool FIRST>
-__device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw, const double (&z)[SH::NV],
-                                              const double (&s)[SH::RT], const double (&lam)[SH::RT],
+__device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw, const double *zv,
+                                              const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
+                                              double (&dd)[SH::RD > 0 ? SH::RD : 1],
                                               double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
     constexpr int NV = SH::NV, NDP = SH::NDP, NT = SH::NT;
     constexpr int TRI = col_off<NV>(J1) - col_off<NV>(J0);
@@ -283,14 +311,16 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
         double g[NV];
 #pragma unroll
         for (int j = I0; j < NV; ++j) g[j] = Gt[j * NDP + r];
-        const double rsk = (r < nd) ? fast_rcp(s[k]) : 0.0;
-        const double d = lam[k] * rsk;
+        // padding rows carry s = 1, lam = 0, g = 0, h = 1: d = 0 and r_p = 0 without any masking
+        if (FIRST) dd[k] = lam[k] * fast_rcp(s[k]);
+        const double d = dd[k];
         if (FIRST) {
             double gz0 = 0.0, gz1 = 0.0;
 #pragma unroll
-            for (int j = 0; j + 1 < NV; j += 2) { gz0 += g[j] * z[j]; gz1 += g[j + 1] * z[j + 1]; }
-            if (NV & 1) gz0 += g[NV - 1] * z[NV - 1];
+            for (int j = 0; j + 1 < NV; j += 2) { gz0 += g[j] * zv[j]; gz1 += g[j + 1] * zv[j + 1]; }
+            if (NV & 1) gz0 += g[NV - 1] * zv[NV - 1];
             const double rpk = (gz0 + gz1) + s[k] - hw[k * WAVE + lane];
+            rp[k] = rpk;
             gap_l += s[k] * lam[k];
             rpn_l = fmax(rpn_l, fabs(rpk));
             const double t = d * rpk;
@@ -323,20 +353,21 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
 }
 
 template <class SH, int BI>
-__device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double *hw, const double (&z)[SH::NV],
-                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT],
+__device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double *hw, const double *zv,
+                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
+                                                  double (&dd)[SH::RD > 0 ? SH::RD : 1],
                                                   double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
     using BL = Blocks<SH::NV>;
     if constexpr (BI < BL::n) {
-        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
-        sweep_a_dense_all<SH, BI + 1>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
+        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
+        sweep_a_dense_all<SH, BI + 1>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
     }
 }
 
 // The FACTORED rows: kc-wide left factor, so W = Hc' D Hc has only KT entries; one pass.
 template <class SH>
-__device__ __forceinline__ void sweep_a_factored(const double *Hct, const double *hw, const double (&cz)[SH::KCA],
-                                                 const double (&s)[SH::RT], const double (&lam)[SH::RT],
+__device__ __forceinline__ void sweep_a_factored(const double *Hct, const double *hw, const double *czv,
+                                                 const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                                  double &gap_l, double &rpn_l, double *red, double *csums, int lane, int ncc) {
     constexpr int KC = SH::KC, KT = SH::KT, NCCP = SH::NCCP;
     double acc[KT + 2 * KC];
@@ -348,9 +379,10 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
         double hc[KC];
         double gz = 0.0;
 #pragma unroll
-        for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * cz[a]; }
+        for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * czv[a]; }
         const double rpk = gz + s[k] - hw[k * WAVE + lane];
-        const double rsk = (rc < ncc) ? fast_rcp(s[k]) : 0.0;
+        rp[k] = rpk;
+        const double rsk = fast_rcp(s[k]);          // padding rows: lam = 0, so d = 0
         gap_l += s[k] * lam[k];
         rpn_l = fmax(rpn_l, fabs(rpk));
         const double d = lam[k] * rsk;
@@ -434,6 +466,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *xin = vec + 3 * NV;       // [2*nx] x_k | ref   (nx <= 16)
     double *tv = vec + 3 * NV + 32;   // [NV] scratch
     double *uv = vec + 4 * NV + 32;   // [NV] scratch
+    double *dzav = vec + 5 * NV + 32; // [NV] affine direction
+    double *dzv = vec + 6 * NV + 32;  // [NV] final direction
+    double *czv = vec + 7 * NV + 32;  // [8] Psi z
+    double *cdzav = czv + 8;          // [8] Psi dz_aff
+    double *cdzv = czv + 16;          // [8] Psi dz        (KC <= 8 and 24 <= 2 NV whenever KC > 0)
 
     const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * WPB + wave;
     const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * WPB;
@@ -484,15 +521,16 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             zv[lane] = v;
         }
         wave_lds_fence();
-        double z[NV];
         double qn = 1.0;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) { z[j] = uni(zv[j]); qn = fmax(qn, fabs(qv[j])); }
+        for (int j = 0; j < NV; ++j) qn = fmax(qn, fabs(qv[j]));
 
         double s[RT], lam[RT];
         double smin = INFINITY;
         {
-            double cz[KCA];
+            double z[NV], cz[KCA];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) z[j] = zv[j];
             factor_coords<SH>(Psi, z, cz, lane);
             // unrolled by the template recursion below
             auto init_slot = [&](auto kc_) {
@@ -536,8 +574,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             bool skip_ipm = false;
             if (WARM && (st1 == 0 || st1 == 1)) {
                 // pick up (z, s, lambda) where the streaming kernel left them
-#pragma unroll
-                for (int j = 0; j < NV; ++j) z[j] = uni(warm.z[b * NV + j]);
+                if (lane < NV) zv[lane] = warm.z[b * NV + lane];
 #pragma unroll
                 for (int k = 0; k < RT; ++k) {
                     const int gid = k < RD ? lane + k * WAVE : nd + lane + (k - RD) * WAVE;
@@ -545,8 +582,6 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     s[k] = valid ? warm.s[b * warm.ncp + gid] : 1.0;
                     lam[k] = valid ? warm.lam[b * warm.ncp + gid] : 0.0;
                 }
-#pragma unroll
-                for (int j = 0; j < NV; ++j) if (lane == j) zv[j] = z[j];
                 wave_lds_fence();
                 it = warm.it[b];
                 it_done = it;
@@ -563,13 +598,18 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             } else
             for (; it < qp.max_iter; ++it) {
                 it_done = it;
-                // ---- sweeps A: residuals, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam
+                // ---- sweeps A: residuals, G'DG (dense rows by column blocks, factored rows as W), G'(d.rp), G'lam.
+                // r_p is kept per row for sweeps B and D; the iterate z and the directions live in LDS only.
                 double gap_l = 0.0, rpn_l = 0.0;
-                if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, z, s, lam, gap_l, rpn_l, red, sums, lane, nd);
-                double cz[KCA];                 // Psi z, shared by the three sweeps of this iteration
+                double rp[RT];
+                {
+                    double dd[RD > 0 ? RD : 1];
+                    if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
+                }
                 if constexpr (KC > 0) {
-                    factor_coords<SH>(Psi, z, cz, lane);
-                    sweep_a_factored<SH>(Hct, hw, cz, s, lam, gap_l, rpn_l, red, csums, lane, ncc);
+                    coords_lds<SH>(Psi, zv, czv, lane);
+                    wave_lds_fence();
+                    sweep_a_factored<SH>(Hct, hw, czv, s, lam, rp, gap_l, rpn_l, red, csums, lane, ncc);
                     // fold the factored block into the dense totals: P = W Psi now, Psi' P when the rows are loaded
                     for (int idx = lane; idx < KC * NV; idx += WAVE) {
                         const int a = idx / NV, j = idx - a * NV;
@@ -613,7 +653,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 for (int j = 0; j < NV; ++j) {
                     const double cgj = cgv[j], qj = qv[j];
                     rdn = fmax(rdn, fabs(cgj + sums[NT + NV + j]));
-                    obj += z[j] * (0.5 * (cgj - qj) + qj);
+                    obj += zv[j] * (0.5 * (cgj - qj) + qj);
                 }
                 if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
                 const double objs = fmax(fabs(obj), 1.0);
@@ -634,7 +674,6 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 }
                 // ---- M = Hs + G'DG by rows (lane i holds row i), elimination with the predictor rhs carried along
                 double mrow[NV], mdinv = 1.0, rhs_i = 0.0;
-                double dz[NV];
                 {
                     const int li = lane < NV ? lane : 0;
                     double shift = 0.0;
@@ -656,7 +695,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         mdinv = 1.0;
                         spd = rows_factor<NV>(mrow, bb, mdinv, lane);
                         if (spd) {
-                            rows_backsub<NV>(mrow, bb, mdinv, dz);
+                            const double xl = rows_backsub_lane<NV>(mrow, bb, mdinv, lane);
+                            if (lane < NV) dzav[lane] = xl;
                         } else {
                             // non-positive pivot from cancellation: retry once with a 1e-13 * trace shift
                             double trc = 0.0;
@@ -667,29 +707,27 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     }
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
                 }
+                wave_lds_fence();
+                if constexpr (KC > 0) { coords_lds<SH>(Psi, dzav, cdzav, lane); wave_lds_fence(); }
                 STAMP(3);
-                // ---- sweep B: affine step statistics and the corrector's G' products (r_p, 1/s recomputed per row)
-                double dza[NV];
-#pragma unroll
-                for (int j = 0; j < NV; ++j) dza[j] = dz[j];
+                // ---- sweep B: affine step statistics and the corrector's G' products; w = ds_aff * dl_aff kept per row
                 double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
-                double cdza[KCA];               // Psi dza, shared by sweeps B and D
+                double wv[RT];
                 double v2 = 0.0, v3 = 0.0;          // lane i < NV: entries i of G'(dsa.dla/s) and G'(1/s)
                 {
-                    if constexpr (KC > 0) factor_coords<SH>(Psi, dza, cdza, lane);
-                    const double (&cdz)[KCA] = cdza;
-                    // returns (dsa*dla/s, 1/s) of the row
-                    auto row_stats = [&](int k, bool valid, double gz, double gdz, double hk, double &c1, double &rsk) {
-                        rsk = valid ? fast_rcp(s[k]) : 0.0;
-                        const double rpk = gz + s[k] - hk;
-                        const double dsa = valid ? (-rpk - gdz) : 0.0;
-                        const double dla = valid ? (-lam[k] - lam[k] * rsk * dsa) : 0.0;
+                    // returns (dsa*dla/s, 1/s) of the row; padding rows (s = 1, lam = 0, g = 0, r_p = 0) give zeros by themselves
+                    auto row_stats = [&](int k, bool valid, double gdz, double &c1, double &rsk) {
+                        const double rs0 = fast_rcp(s[k]);
+                        const double dsa = -rp[k] - gdz;
+                        const double dla = -lam[k] - lam[k] * rs0 * dsa;
                         const double rl = valid ? fast_rcp(lam[k]) : 0.0;
-                        rho_aff = fmax(rho_aff, fmax(-dsa * rsk, -dla * rl));
+                        rho_aff = fmax(rho_aff, fmax(-dsa * rs0, -dla * rl));
                         const double w = dsa * dla;
                         sb1 += s[k] * dla + lam[k] * dsa;
                         sb2 += w;
-                        c1 = w * rsk;
+                        wv[k] = w;
+                        c1 = w * rs0;
+                        rsk = valid ? rs0 : 0.0;
                     };
                     if constexpr (RD > 0) {
                         double accb[2 * NV];
@@ -699,11 +737,14 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         for (int k = 0; k < RD; ++k) {
                             const int r = lane + k * WAVE;
                             double g[NV];
-                            double gz = 0.0, gdz = 0.0;
+                            double gd0 = 0.0, gd1 = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) { g[j] = Gt[j * NDP + r]; gz += g[j] * z[j]; gdz += g[j] * dza[j]; }
+                            for (int j = 0; j < NV; ++j) g[j] = Gt[j * NDP + r];
+#pragma unroll
+                            for (int j = 0; j + 1 < NV; j += 2) { gd0 += g[j] * dzav[j]; gd1 += g[j + 1] * dzav[j + 1]; }
+                            if (NV & 1) gd0 += g[NV - 1] * dzav[NV - 1];
                             double c1, rsk;
-                            row_stats(k, r < nd, gz, gdz, hw[k * WAVE + lane], c1, rsk);
+                            row_stats(k, r < nd, gd0 + gd1, c1, rsk);
 #pragma unroll
                             for (int j = 0; j < NV; ++j) { accb[j] += g[j] * c1; accb[NV + j] += g[j] * rsk; }
                             row_fence();
@@ -718,13 +759,14 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         for (int k = RD; k < RT; ++k) {
                             const int rc = lane + (k - RD) * WAVE;
                             double hc[KC];
-                            double gz = 0.0, gdz = 0.0;
+                            double gdz = 0.0;
 #pragma unroll
-                            for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * cz[a]; gdz += hc[a] * cdz[a]; }
+                            for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gdz += hc[a] * cdzav[a]; }
                             double c1, rsk;
-                            row_stats(k, rc < ncc, gz, gdz, hw[k * WAVE + lane], c1, rsk);
+                            row_stats(k, rc < ncc, gdz, c1, rsk);
 #pragma unroll
                             for (int a = 0; a < KC; ++a) { accc[a] += hc[a] * c1; accc[KC + a] += hc[a] * rsk; }
+                            row_fence();
                         }
                         wave_reduce_to_lds<2 * KC>(accc, red, csums + KT, lane);
                     }
@@ -748,35 +790,44 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 {
                     double bb = (lane < NV) ? rhs_i + v2 - smu * v3 : 0.0;
                     rows_forward<NV>(mrow, bb, lane);
-                    rows_backsub<NV>(mrow, bb, mdinv, dz);
+                    const double xl = rows_backsub_lane<NV>(mrow, bb, mdinv, lane);
+                    if (lane < NV) dzv[lane] = xl;
                 }
+                wave_lds_fence();
+                if constexpr (KC > 0) { coords_lds<SH>(Psi, dzv, cdzv, lane); wave_lds_fence(); }
                 STAMP(5);
-                // ---- sweep D: final direction, step length, update (row quantities recomputed once more)
+                // ---- sweep D: final direction, step length, update
                 double dsv[RT], dlv[RT];
                 double om = (1.0 - aaff) * (1.0 - aaff);
                 om = fmin(fmax(om, 1e-4), 1e-2);
                 const double tau = 1.0 - om;
                 double rho = 0.0;
                 {
-                    double cdz[KCA];
-                    if constexpr (KC > 0) factor_coords<SH>(Psi, dz, cdz, lane);
                     auto step_row = [&](auto kc_) {
                         constexpr int k = decltype(kc_)::value;
                         const bool valid = slot_valid<SH>(k, lane, nd, ncc);
-                        double gz, gdza, gdz;
-                        row_dots<SH, k, true>(Gt, Hct, z, cz, dza, cdza, dz, cdz, lane, gz, gdza, gdz);
-                        const double rsk = valid ? fast_rcp(s[k]) : 0.0;
-                        const double rpk = gz + s[k] - hw[k * WAVE + lane];
-                        const double dsa = -rpk - gdza;
-                        const double dla = -lam[k] - lam[k] * rsk * dsa;
-                        const double dsk = valid ? (-rpk - gdz) : 0.0;
-                        const double rc = s[k] * lam[k] + dsa * dla - smu;
-                        const double dlk = valid ? (-(rc + lam[k] * dsk) * rsk) : 0.0;
+                        double gdz = 0.0;
+                        if constexpr (k < RD) {
+                            const int r = lane + k * WAVE;
+                            double g0 = 0.0, g1 = 0.0;
+#pragma unroll
+                            for (int j = 0; j + 1 < NV; j += 2) { g0 += Gt[j * NDP + r] * dzv[j]; g1 += Gt[(j + 1) * NDP + r] * dzv[j + 1]; }
+                            if (NV & 1) g0 += Gt[(NV - 1) * NDP + r] * dzv[NV - 1];
+                            gdz = g0 + g1;
+                        } else {
+                            const int rc = lane + (k - RD) * WAVE;
+#pragma unroll
+                            for (int a = 0; a < KC; ++a) gdz += Hct[a * NCCP + rc] * cdzv[a];
+                        }
+                        const double rs0 = fast_rcp(s[k]);
+                        const double dsk = -rp[k] - gdz;
+                        const double rc2 = s[k] * lam[k] + wv[k] - smu;
+                        const double dlk = valid ? (-(rc2 + lam[k] * dsk) * rs0) : 0.0;
                         const double rl = valid ? fast_rcp(lam[k]) : 0.0;
-                        rho = fmax(rho, fmax(-dsk * rsk, -dlk * rl));
+                        rho = fmax(rho, fmax(-dsk * rs0, -dlk * rl));
                         dsv[k] = dsk;
                         dlv[k] = dlk;
-                        if constexpr (k < RD) row_fence();
+                        row_fence();
                     };
                     [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (step_row(std::integral_constant<int, Ks>{}), ...); }
                     (std::make_integer_sequence<int, RT>{});
@@ -785,10 +836,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 const double alpha = rho > tau ? tau / rho : 1.0;
 #pragma unroll
                 for (int k = 0; k < RT; ++k) { s[k] += alpha * dsv[k]; lam[k] += alpha * dlv[k]; }
-#pragma unroll
-                for (int j = 0; j < NV; ++j) z[j] = uni(z[j] + alpha * dz[j]);
-#pragma unroll
-                for (int j = 0; j < NV; ++j) if (lane == j) zv[j] = z[j];     // z is wave-uniform
+                if (lane < NV) zv[lane] += alpha * dzv[lane];
                 wave_lds_fence();
                 it_done = it + 1;
                 STAMP(6);
@@ -810,7 +858,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 for (int k = 0; k < RT; ++k) { inW[k] = slot_valid<SH>(k, lane, nd, ncc) && (lam[k] > s[k]); yall[k] = lam[k]; }
                 double zp[NV];
 #pragma unroll
-                for (int j = 0; j < NV; ++j) zp[j] = z[j];
+                for (int j = 0; j < NV; ++j) zp[j] = zv[j];
                 for (int round = 0; round < 6 && !ok; ++round) {
                     // compact the working set: W[0..m)
                     int m = 0;
@@ -987,7 +1035,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     if (nviol == 0 && nneg == 0) {
                         ok = true;
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) z[j] = zp[j];
+                        for (int j = 0; j < NV; ++j) if (lane == j) zv[j] = zp[j];
 #pragma unroll
                         for (int k = 0; k < RT; ++k) {
                             lam[k] = inW[k] ? fmax(yall[k], 0.0) : 0.0;
@@ -1004,7 +1052,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (st == TMPC_STATUS_MAX_ITER) {
                 // iteration cap: if the iterate still violates the constraints, call it infeasible
                 double viol = 0.0;
-                double cz[KCA];
+                double z[NV], cz[KCA];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) z[j] = zv[j];
                 if constexpr (KC > 0) factor_coords<SH>(Psi, z, cz, lane);
                 auto viol_slot = [&](auto kc_) {
                     constexpr int k = decltype(kc_)::value;
@@ -1023,8 +1073,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         const double nanv = __longlong_as_double(0x7ff8000000000000ll);
         // zu = Dv .* z -> zv (LDS) so that any lane can read any entry
         wave_lds_fence();
-#pragma unroll
-        for (int j = 0; j < NV; ++j) if (lane == j) zv[j] = (j < qp.nv) ? qp.Dv[j] * z[j] : 0.0;
+        if (lane < NV) zv[lane] = (lane < qp.nv) ? qp.Dv[lane] * zv[lane] : 0.0;
         wave_lds_fence();
         for (int i = lane; i < N * nu; i += WAVE) u_nom[b * N * nu + i] = good ? zv[i] : nanv;
         if (lane < nx + nu) {
