@@ -67,12 +67,16 @@ def draw_realisations(n_traj: int, T: int, w_bound, seed: int = 20240301, first:
     return th, ga, w
 
 
-def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None):
+def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False):
     """Closed loop of the remote tube-based MPC over a lossy network for a batch of trajectories:
     the body of the reference's Monte-Carlo loop (results_linear_system.py:209-259, 291) with the
     per-trajectory objects replaced by the batched state machines and the QP solves of one time
-    step done by ONE call of `packets_fn(x_hat (B,nx), ref_t (B,nx)) -> (U_t (B,nu,N+1), x_nom0,
-    status (B,))` -- normally `TubeTrackingMPC.determine_packets`, i.e. one kernel launch.
+    step done by ONE call of `packets_fn(x_hat (B,nx), ref_t (B,nx)[, gamma (B,)]) -> (U_t (B,nu,N+1),
+    x_nom0, status (B,))` -- normally `TubeTrackingMPC.determine_packets`, i.e. one kernel launch.
+
+    extended=True is the loop of results_linear_system_with_extendedMPC.py:247-378: the controller is an
+    ExtendedTubeTrackingMPC that is told whether the previous plant packet arrived (gamma_{t-1}, :276), the
+    estimator is the RobustEstimator (it also stores x_nom_0, :279) and the actuator adopts x_nom_0 (:133-147).
 
     p_loss (B,), ref (T,) position reference, th_u/ga_u (B,T) uniforms, w (B,T,nx) disturbances.
     Returns a dict of per-trajectory statistics."""
@@ -84,34 +88,43 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     nx = A.shape[0]
     p_loss = np.asarray(p_loss, dtype=np.float64).reshape(nb)
     x = np.zeros((nb, nx)) if x0 is None else np.array(x0, dtype=np.float64).reshape(nb, nx)
-    est = BatchedEstimator(A, Bm, K, x, N)
-    act = BatchedConsistentActuator(A, Bm, K, K_plant, x)
+    est = BatchedEstimator(A, Bm, K, x, N, K_plant=K_plant if extended else None, robust=extended)
+    act = BatchedConsistentActuator(A, Bm, K, K_plant, x, is_extended_MPC_used=extended)
     err2 = np.zeros(nb)
     tube_viol = np.zeros(nb, dtype=np.int32)
     not_optimal = np.zeros(nb, dtype=np.int32)
     consistent_err = 0.0
-    U_prev = None
+    U_prev = x0_prev = None
+    gamma = np.ones(nb, dtype=np.int64)
     for t in range(T):
         theta = np.where(th_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :211-226, strict <
-        gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)
         r_t = np.zeros((nb, nx))
         r_t[:, 0] = ref[t]
         q_t = est.get_qt()
-        U_t, _, status = packets_fn(est.get_estimate(), r_t)                                       # :240
+        if extended:
+            U_t, x_nom_0, status = packets_fn(est.get_estimate(), r_t, gamma.astype(np.uint8))     # RLX:276, gamma of step t-1
+        else:
+            U_t, x_nom_0, status = packets_fn(est.get_estimate(), r_t)                             # :240
         bad = status >= 2
         not_optimal += (status != 0)
         if bad.any():
             # the reference's tube branch has no handling for a failed solve (it would raise); here the
             # packet of such a trajectory is treated as lost and its previous sequence stays in use
             U_t = np.where(bad[:, None, None], U_prev if U_prev is not None else 0.0, U_t)
+            x_nom_0 = np.where(bad[:, None], x0_prev if x0_prev is not None else 0.0, x_nom_0)
             theta = np.where(bad, 0, theta)
-        U_prev = U_t
+        U_prev, x0_prev = U_t, x_nom_0
         est.store(U_t)                                                                             # :242
-        x_nom_t = act.x_nom.copy()
-        u, pkt = act.process(U_t, q_t, x, theta)                                                   # :244
+        if extended:
+            est.store_x_nom_0(x_nom_0)                                                             # RLX:279
+        u, pkt = act.process(U_t, q_t, x, theta, x_nom_0 if extended else None)                    # :244
         err2 += (x[:, 0] - ref[t]) ** 2 + np.sum(x[:, 1:] ** 2, axis=1)                            # :291 (x_t, t = 0..T-1)
-        tube_viol += ~np.asarray(Z.contains((x - x_nom_t).T)).reshape(nb)                          # :258
+        # :258 -- plant state against the nominal state the actuator used at time t (for the extended controller:
+        # after adopting the packet's x_nom_0, SmartActuator.py:219-222)
+        x_nom_now = pkt["x_nom_t"] if extended else pkt["x_t"]
+        tube_viol += ~np.asarray(Z.contains((x - x_nom_now).T)).reshape(nb)
         x = x @ A.T + u @ Bm.T + w[:, t]                                                           # :248
+        gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :218-226
         est.update(pkt, gamma)                                                                     # :254
         # Proposition 1 of the paper: whenever the actuator is consistent and the plant packet arrives,
         # the estimate equals the nominal plant state
@@ -120,3 +133,27 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
             consistent_err = max(consistent_err, float(np.max(np.abs(est.x_hat[ok] - act.x_nom[ok]))))
     return dict(tracking_error=np.sqrt(err2) / T, tube_violations=tube_viol, not_optimal=not_optimal,
                 consistent_estimate_error=consistent_err, x_final=x)
+
+
+def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
+             extended: bool = False, device=None):
+    """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
+    trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
+    shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
+    Returns (table (n_total, 3) = [tracking error, tube violations, non-optimal solves], p_index (n_total,)),
+    identical on every rank."""
+    import torch
+    p_loss = np.asarray(p_loss, dtype=np.float64)
+    pi, _ = trajectory_table(p_loss, n_mc)
+    n_total = len(pi)
+    lo, hi = shard_bounds(n_total, rank, world)
+    th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
+    ref = np.broadcast_to(np.asarray(ref, dtype=np.float64), (T,))
+    out = run_remote_tube_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
+                              mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, p_loss[pi[lo:hi]], ref, th, ga, w,
+                              extended=extended)
+    local = torch.tensor(np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]], dtype=torch.float64)
+    if device is not None:
+        local = local.to(device)
+    table = gather_statistics(local, n_total, rank, world)
+    return table.cpu().numpy(), pi

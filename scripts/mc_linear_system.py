@@ -1,0 +1,57 @@
+"""Monte-Carlo sweep over packet-loss rates on the GPU(s): counterpart of the reference's
+Results/results_linear_system.py (tube MPC part) and ..._with_extendedMPC.py.
+
+    python scripts/mc_linear_system.py --n-mc 20 --T 250 --N 20 [--extended]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 scripts/mc_linear_system.py ...
+
+One process per GPU; the sweep is sharded over the ranks, the statistics table is all-gathered (RCCL)."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+import common  # noqa: E402  (cached offline sets of the cartpole)
+from LinearMPCOverNetworks import montecarlo  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-mc", type=int, default=20)            # results_linear_system.py:147
+    ap.add_argument("--T", type=int, default=250)              # :143
+    ap.add_argument("--N", type=int, default=20)               # :64
+    ap.add_argument("--ref", type=float, default=0.5)          # :160
+    ap.add_argument("--extended", action="store_true")
+    args = ap.parse_args()
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    import torch
+    device = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+        device = torch.device("cuda", local)
+    mpc, model = common.make_mpc("cartpole", args.N, True, extended=args.extended, create=True, device=local)
+    p_loss = np.arange(10) / 10.0                              # :149
+    t0 = time.time()
+    table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
+                                    extended=args.extended, device=device)
+    dt = time.time() - t0
+    if rank == 0:
+        n = len(pi)
+        print(f"{n} trajectories x {args.T} steps = {n * args.T} solves in {dt:.2f} s on {world} GPU(s): {n * args.T / dt:.3e} MPC steps/s (end to end)")
+        print("p_loss  mean tracking error   tube violations   non-optimal solves")
+        for i, p in enumerate(p_loss):
+            m = pi == i
+            print(f"{p:5.1f}   {table[m, 0].mean():.6f}            {int(table[m, 1].sum()):6d}            {int(table[m, 2].sum()):6d}")
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -10,16 +10,16 @@ from oracle.oracle import Oracle
 
 
 def _oracle_packets(mpc, orc):
-    def fn(x_hat, r):
-        sol = orc.solve(x_hat, r)
+    def fn(x_hat, r, gamma=None):
+        sol = orc.solve(x_hat, r, gamma)
         u_ss = sol["u_ss"] + sol["x_ss"] @ mpc._K.T                        # TubeTrackingMPC.py:217
         U = np.concatenate([sol["u_nom"], u_ss[:, None, :]], axis=1).transpose(0, 2, 1)
         return np.ascontiguousarray(U), sol["x_nom0"], sol["status"]
     return fn
 
 
-def _setup(nb, T, seed=7):
-    mpc, w = common.make_mpc("cartpole", 10, True)
+def _setup(nb, T, seed=7, extended=False):
+    mpc, w = common.make_mpc("cartpole", 10, True, extended=extended)
     p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
     th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=seed)
     ref = 0.5 * np.ones(T)
@@ -42,15 +42,43 @@ def test_closed_loop_invariants_cpu(oracle_lib):
     assert np.array_equal(th1[0], th[5]) and np.array_equal(d1[0], dist[5])
 
 
+def test_extended_closed_loop_invariants_cpu(oracle_lib):
+    """results_linear_system_with_extendedMPC.py:247-378: ExtendedTubeTrackingMPC + RobustEstimator +
+    ConsistentActuator(is_extended_MPC_used=True); the controller is told gamma_{t-1}."""
+    nb, T = 8, 40
+    mpc, w, p_loss, th, ga, dist, ref = _setup(nb, T, extended=True)
+    orc = Oracle(mpc._problem_dict())
+    K = mpc.get_steady_state_controller_gain()
+    seen = []
+
+    def fn(x_hat, r, gamma):
+        seen.append(gamma.copy())
+        return _oracle_packets(mpc, orc)(x_hat, r, gamma)
+    out = montecarlo.run_remote_tube_mpc(fn, w["A"], w["B"], K, mpc.get_ancillary_controller_gain(), 10, mpc._Z, p_loss, ref,
+                                         th, ga, dist, extended=True)
+    assert np.all(out["not_optimal"] == 0)
+    assert np.all(out["tube_violations"] == 0)
+    assert np.all(np.isfinite(out["tracking_error"])) and out["tracking_error"].max() < 0.2
+    # gamma handed to the controller at step t is the plant-packet arrival of step t-1 (first step: 1)
+    assert np.all(seen[0] == 1)
+    g1 = np.where(ga[:, 1] < p_loss, 0, 1)
+    assert np.array_equal(seen[2], g1.astype(np.uint8)) and np.all(seen[1] == 1)
+    # loss-free trajectories: both problems are used and the packet-received one dominates
+    assert np.all(np.array(seen)[:, p_loss == 0.0] == 1)
+
+
 @pytest.mark.gpu
-def test_closed_loop_gpu_matches_oracle_loop(hip_lib, oracle_lib):
+@pytest.mark.parametrize("extended", [False, True])
+def test_closed_loop_gpu_matches_oracle_loop(hip_lib, oracle_lib, extended):
     nb, T = 64, 60
-    mpc, w, p_loss, th, ga, dist, ref = _setup(nb, T, seed=11)
-    mpc_gpu, _ = common.make_mpc("cartpole", 10, True, create=True)
+    mpc, w, p_loss, th, ga, dist, ref = _setup(nb, T, seed=11, extended=extended)
+    mpc_gpu, _ = common.make_mpc("cartpole", 10, True, extended=extended, create=True)
     orc = Oracle(mpc._problem_dict())
     K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
-    a = montecarlo.run_remote_tube_mpc(mpc_gpu.determine_packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist)
-    b = montecarlo.run_remote_tube_mpc(_oracle_packets(mpc, orc), w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist)
+    a = montecarlo.run_remote_tube_mpc(mpc_gpu.determine_packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist,
+                                       extended=extended)
+    b = montecarlo.run_remote_tube_mpc(_oracle_packets(mpc, orc), w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist,
+                                       extended=extended)
     assert np.all(a["not_optimal"] == 0) and np.all(a["tube_violations"] == 0)
     np.testing.assert_allclose(a["x_final"], b["x_final"], atol=1e-7, rtol=0)
     np.testing.assert_allclose(a["tracking_error"], b["tracking_error"], atol=1e-9, rtol=0)
