@@ -169,6 +169,33 @@ int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch);
 int tmpc_set_kernel_path(tmpc_handle *h, int path);
 int tmpc_get_kernel_path(const tmpc_handle *h, int variant);
 
+/*
+ * Device-resident closed loop over a lossy network for B independent trajectories and T time steps: the body
+ * of the reference's Monte-Carlo loop (Results/results_linear_system.py:209-259,291; with extended != 0
+ * results_linear_system_with_extendedMPC.py:247-378) -- controller packet, packet losses in both directions,
+ * consistent actuator with nominal model and ancillary feedback (SmartActuator.py:125-231), plant update,
+ * estimator / robust estimator (Estimator.py:9-161) -- run as per-trajectory state machines between the solve
+ * launches, on the handle's stream; only the statistics return to the host.
+ *
+ *   in   p_loss B        loss probability of the trajectory (both directions)
+ *        ref    T        position reference; the solve gets ref_t = [ref[t], 0, ...]   (:240)
+ *        th_u   B*T      uniforms: controller->plant packet of step t is lost iff t > 0 and th_u < p_loss
+ *        ga_u   B*T      same for the plant->controller packet
+ *        w      B*T*nx   disturbance realisations
+ *        x0     B*nx or NULL (zeros)
+ *        HZ,hZ  rZ x nx, rZ   the tube cross-section Z for the membership check (:258); rZ = 0 skips it
+ *   out  (any may be NULL)
+ *        err2        B   sum_t (x_t[0]-ref_t)^2 + |x_t[1:]|^2   (tracking error of :291 = sqrt(err2)/T)
+ *        tube_viol   B   steps with x_t - x_nom_t outside Z
+ *        not_optimal B   solves with status != 0 (a solve with status >= 2 sends no packet)
+ *        x_final     B*nx
+ *        consistent  B   max |x_hat - x_nom| over the steps with Theta_t = gamma_t = 1 (0 by Proposition 1; not for extended)
+ * All pointers are HOST pointers; the call returns when the results are in place.
+ */
+int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
+                const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
+                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent);
+
 /* Block until everything enqueued on the handle's stream has finished. */
 int tmpc_synchronize(tmpc_handle *h);
 

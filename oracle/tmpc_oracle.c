@@ -510,7 +510,9 @@ static int polish(const form_t *f, work_t *w) {
         }
         for (int k = 0; k < m; ++k) if (w->y[k] < -1e-10 * ymax) ++nneg;
         if (getenv("ORACLE_DEBUG")) fprintf(stderr, "   polish it %d m %d nviol %d nneg %d nloose %d\n", it, m, nviol, nneg, nloose);
-        if (nloose) return 0;
+        /* rows of W off their bound with nothing left to correct: the steps have not converged, give up.
+         * (With wrong rows still in W the system is inconsistent and looseness is expected: correct W first.) */
+        if (nloose && nviol == 0 && nneg == 0) return 0;
         if (nviol == 0 && nneg == 0) {
             memcpy(w->z, w->zp, sizeof(double) * nv);
             for (int i = 0; i < nc; ++i) { w->lam[i] = 0; w->s[i] = w->r[i] < 0 ? -w->r[i] : 0; }

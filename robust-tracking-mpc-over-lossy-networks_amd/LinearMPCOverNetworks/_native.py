@@ -87,6 +87,8 @@ def lib():
         L.tmpc_set_kernel_path.restype = C.c_int
         L.tmpc_get_kernel_path.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_get_kernel_path.restype = C.c_int
+        L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 5
+        L.tmpc_mc_run.restype = C.c_int
         L.tmpc_synchronize.argtypes = [C.c_void_p]
         L.tmpc_synchronize.restype = C.c_int
         L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -255,3 +257,29 @@ def get_kernel_path(h: Handle, variant: int = 0) -> str:
     if code < 0:
         raise RuntimeError("tmpc_get_kernel_path failed")
     return {v: k for k, v in KERNEL_PATHS.items()}[code]
+
+
+def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False) -> dict:
+    """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device."""
+    c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    th_u, ga_u, w, p_loss, ref = c(th_u), c(ga_u), c(w), c(p_loss), c(ref)
+    B, T = th_u.shape
+    if ga_u.shape != (B, T) or w.shape != (B, T, h.nx) or p_loss.shape != (B,) or ref.shape != (T,):
+        raise ValueError("mc_run: inconsistent shapes")
+    x0c = None if x0 is None else c(x0).reshape(B, h.nx)
+    HZ = hZ = None
+    rZ = 0
+    if Z is not None:
+        HZ, hZ = c(Z.A), c(Z.b)
+        rZ = HZ.shape[0]
+    out = dict(err2=np.empty(B), tube_violations=np.empty(B, np.int32), not_optimal=np.empty(B, np.int32),
+               x_final=np.empty((B, h.nx)), consistent=np.empty(B))
+    ptr = lambda a: None if a is None else a.ctypes.data
+    rc = lib().tmpc_mc_run(h.ptr, B, T, int(bool(extended)), ptr(p_loss), ptr(ref), ptr(th_u), ptr(ga_u), ptr(w), ptr(x0c),
+                           ptr(HZ), ptr(hZ), rZ, ptr(out["err2"]), ptr(out["tube_violations"]), ptr(out["not_optimal"]),
+                           ptr(out["x_final"]), ptr(out["consistent"]))
+    if rc != 0:
+        raise RuntimeError(f"tmpc_mc_run failed ({rc}): {h.error()}")
+    out["tracking_error"] = np.sqrt(out["err2"]) / T
+    out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
+    return out

@@ -136,7 +136,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
 
 
 def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
-             extended: bool = False, device=None):
+             extended: bool = False, device=None, on_device: bool = False):
     """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
     trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
     shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
@@ -149,9 +149,12 @@ def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240
     lo, hi = shard_bounds(n_total, rank, world)
     th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
     ref = np.broadcast_to(np.asarray(ref, dtype=np.float64), (T,))
-    out = run_remote_tube_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
-                              mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, p_loss[pi[lo:hi]], ref, th, ga, w,
-                              extended=extended)
+    if on_device:        # state machines on the GPU as well (tmpc_mc_run); otherwise the host loop around determine_packets
+        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended)
+    else:
+        out = run_remote_tube_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
+                                  mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, p_loss[pi[lo:hi]], ref, th, ga, w,
+                                  extended=extended)
     local = torch.tensor(np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]], dtype=torch.float64)
     if device is not None:
         local = local.to(device)

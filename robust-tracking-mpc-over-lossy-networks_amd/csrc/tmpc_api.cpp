@@ -50,6 +50,7 @@ struct tmpc_handle {
     int ws_ncp = 0;
     double *ws_s = nullptr, *ws_lam = nullptr, *ws_z = nullptr;
     int32_t *ws_stat = nullptr, *ws_it = nullptr;
+    std::vector<double> hA, hB, hK, hKanc;   // host copies for the closed-loop entry point
     int kernel_path = TMPC_PATH_AUTO;
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
     int blk_ncp = 0;
@@ -346,6 +347,10 @@ int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
     tmpc_handle *h = new (std::nothrow) tmpc_handle();
     if (!h) { g_create_error = "out of memory"; return TMPC_E_NOMEM; }
     h->device = device; h->nx = p->nx; h->nu = p->nu; h->N = p->N;
+    h->hA.assign(p->A ? p->A : nullptr, p->A ? p->A + p->nx * p->nx : nullptr);
+    h->hB.assign(p->B ? p->B : nullptr, p->B ? p->B + p->nx * p->nu : nullptr);
+    if (p->K) h->hK.assign(p->K, p->K + p->nu * p->nx);
+    if (p->K_anc) h->hKanc.assign(p->K_anc, p->K_anc + p->nu * p->nx);
     h->nvariants = p->extended ? 2 : 1;
     int rc = TMPC_OK;
     try {
@@ -469,6 +474,88 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
     if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
     if (h->device < 0) return TMPC_PATH_AUTO;
     return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;
+}
+
+int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
+                const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
+                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent) {
+    if (!h) return TMPC_E_INVALID;
+    if (B < 0 || T < 0 || !p_loss || !ref || !th_u || !ga_u || !w || (rZ > 0 && (!HZ || !hZ))) { h->err = "tmpc_mc_run: NULL argument"; return TMPC_E_INVALID; }
+    if (h->device < 0) { h->err = "host-only handle (device < 0): nothing can be solved without the GPU"; return TMPC_E_DEVICE; }
+    if (extended && h->nvariants < 2) { h->err = "tmpc_mc_run: extended loop needs a problem created with extended = 1"; return TMPC_E_INVALID; }
+    if (h->hK.empty() || h->hKanc.empty()) { h->err = "tmpc_mc_run: the problem description carries no gains K / K_anc"; return TMPC_E_INVALID; }
+    if (h->nu > 16) { h->err = "tmpc_mc_run: nu <= 16"; return TMPC_E_UNSUPPORTED; }
+    if (B == 0 || T == 0) return TMPC_OK;
+    HIP_TRY(h, hipSetDevice(h->device));
+    int rc = ensure_staging(h, B);
+    if (rc) return rc;
+    const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
+    std::vector<void *> tmp;
+    auto dalloc = [&](size_t bytes, void **out) -> int {
+        HIP_TRY(h, hipMalloc(out, bytes ? bytes : 8));
+        tmp.push_back(*out);
+        return TMPC_OK;
+    };
+    auto up = [&](const void *src, size_t bytes, const void **out) -> int {
+        void *q2 = nullptr;
+        int r2 = dalloc(bytes, &q2);
+        if (r2) return r2;
+        HIP_TRY(h, hipMemcpyAsync(q2, src, bytes, hipMemcpyHostToDevice, h->stream));
+        *out = q2;
+        return TMPC_OK;
+    };
+    auto run = [&]() -> int {
+        tmpc::McModel m{};
+        tmpc::McState st{};
+        m.nx = h->nx; m.nu = h->nu; m.N = h->N; m.extended = extended ? 1 : 0; m.rZ = rZ;
+        int r2;
+        if ((r2 = up(h->hA.data(), nx * nx * 8, reinterpret_cast<const void **>(&m.A)))) return r2;
+        if ((r2 = up(h->hB.data(), nx * nu * 8, reinterpret_cast<const void **>(&m.B)))) return r2;
+        if ((r2 = up(h->hK.data(), nu * nx * 8, reinterpret_cast<const void **>(&m.K)))) return r2;
+        if ((r2 = up(h->hKanc.data(), nu * nx * 8, reinterpret_cast<const void **>(&m.K_anc)))) return r2;
+        if ((r2 = up(HZ, static_cast<size_t>(rZ) * nx * 8, reinterpret_cast<const void **>(&m.HZ)))) return r2;
+        if ((r2 = up(hZ, static_cast<size_t>(rZ) * 8, reinterpret_cast<const void **>(&m.hZ)))) return r2;
+        if ((r2 = up(p_loss, b * 8, reinterpret_cast<const void **>(&st.p_loss)))) return r2;
+        if ((r2 = up(th_u, b * t_ * 8, reinterpret_cast<const void **>(&st.th_u)))) return r2;
+        if ((r2 = up(ga_u, b * t_ * 8, reinterpret_cast<const void **>(&st.ga_u)))) return r2;
+        if ((r2 = up(w, b * t_ * nx * 8, reinterpret_cast<const void **>(&st.w)))) return r2;
+        struct { void **p; size_t bytes; int fill; } arrays[] = {
+            {reinterpret_cast<void **>(&st.x), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.x_hat), b * nx * 8, 0},
+            {reinterpret_cast<void **>(&st.x_nom), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.Ubuf), b * (N + 1) * nu * 8, 0},
+            {reinterpret_cast<void **>(&st.u_latest0), b * nu * 8, 0}, {reinterpret_cast<void **>(&st.x_nom0_latest), b * nx * 8, 0},
+            {reinterpret_cast<void **>(&st.ref_k), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.err2), b * 8, 0},
+            {reinterpret_cast<void **>(&st.consistent), b * 8, 0}, {reinterpret_cast<void **>(&st.q_est), b * 4, 0},
+            {reinterpret_cast<void **>(&st.q_act), b * 4, 0}, {reinterpret_cast<void **>(&st.s), b * 4, 0},
+            {reinterpret_cast<void **>(&st.Theta), b * 4, 0}, {reinterpret_cast<void **>(&st.last_lost), b * 4, 0xFF},
+            {reinterpret_cast<void **>(&st.tube_viol), b * 4, 0}, {reinterpret_cast<void **>(&st.not_optimal), b * 4, 0},
+            {reinterpret_cast<void **>(&st.gamma), b, 1}};
+        for (auto &a : arrays) {
+            if ((r2 = dalloc(a.bytes, a.p))) return r2;
+            HIP_TRY(h, hipMemsetAsync(*a.p, a.fill, a.bytes, h->stream));        // 0xFF bytes = -1 for last_lost; gamma = 1
+        }
+        if (x0) {
+            HIP_TRY(h, hipMemcpyAsync(st.x, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(st.x_hat, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(st.x_nom, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        for (int t = 0; t < T; ++t) {
+            HIP_TRY(h, tmpc::launch_mc_pre(m, st, t, B, ref[t], h->stream));
+            int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it);
+            if (r3) return r3;
+            HIP_TRY(h, tmpc::launch_mc_post(m, st, t, T, B, ref[t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->stream));
+        }
+        if (err2) HIP_TRY(h, hipMemcpyAsync(err2, st.err2, b * 8, hipMemcpyDeviceToHost, h->stream));
+        if (tube_viol) HIP_TRY(h, hipMemcpyAsync(tube_viol, st.tube_viol, b * 4, hipMemcpyDeviceToHost, h->stream));
+        if (not_optimal) HIP_TRY(h, hipMemcpyAsync(not_optimal, st.not_optimal, b * 4, hipMemcpyDeviceToHost, h->stream));
+        if (x_final) HIP_TRY(h, hipMemcpyAsync(x_final, st.x, b * nx * 8, hipMemcpyDeviceToHost, h->stream));
+        if (consistent) HIP_TRY(h, hipMemcpyAsync(consistent, st.consistent, b * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        return TMPC_OK;
+    };
+    rc = run();
+    if (rc != TMPC_OK) (void)hipStreamSynchronize(h->stream);
+    for (void *q2 : tmp) (void)hipFree(q2);
+    return rc;
 }
 
 int tmpc_synchronize(tmpc_handle *h) {

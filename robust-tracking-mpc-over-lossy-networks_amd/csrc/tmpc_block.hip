@@ -614,7 +614,8 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             if (viol) { inW_[r] = 1; yall_[r] = 0.0; }
                         }
                         block_reduce3<OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
-                        if (nloose != 0.0) break;
+                        // rows of W off their bound with nothing left to correct: not converged, give up (see tmpc_kernels.hip)
+                        if (nloose != 0.0 && nviol == 0.0 && nneg == 0.0) break;
                         if (nviol == 0.0 && nneg == 0.0) {
                             ok = true;
                             if (tid < NVP) zv[tid] = zpv[tid];

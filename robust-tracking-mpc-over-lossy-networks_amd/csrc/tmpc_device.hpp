@@ -85,6 +85,26 @@ hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream);
 
+// Device-resident closed loop (tmpc_mc.hip)
+struct McModel {
+    int nx, nu, N, extended, rZ;
+    const double *A, *B, *K, *K_anc;     // model and gains (row-major)
+    const double *HZ, *hZ;               // tube cross-section Z for the membership check
+};
+struct McState {                         // all [trajectory]-major device arrays
+    double *x, *x_hat, *x_nom;           // plant state, controller-side estimate, plant-side nominal state   [B][nx]
+    double *Ubuf;                        // sequence buffered by the actuator                                  [B][N+1][nu]
+    double *u_latest0, *x_nom0_latest;   // first input / x_nom_0 of the last sequence sent                    [B][nu], [B][nx]
+    double *ref_k;                       // reference handed to the solve                                       [B][nx]
+    double *err2, *consistent;           // statistics                                                          [B]
+    int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal;
+    uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
+    const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
+};
+hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream);
+hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
+                          const double *x_nom0, const double *xu_ss, const int32_t *status, hipStream_t stream);
+
 size_t stream_lds_bytes(int nvp, int ncp, int nx);
 bool stream_supported(int nvp, int ncp, int nx);
 hipError_t launch_stream(const DeviceQP &qp, const StreamQP &sq, int nvp, int variant_id, int64_t B, const double *x_k,

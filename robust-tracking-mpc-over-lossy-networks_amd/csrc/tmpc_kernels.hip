@@ -1031,7 +1031,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         (std::make_integer_sequence<int, RT>{});
                     }
                     wave_lds_fence();
-                    if (nloose != 0) break;
+                    // rows of W off their bound with nothing left to correct: not converged, give up.  (With wrong
+                    // rows still in W the system is inconsistent and looseness is expected: correct W first.)
+                    if (nloose != 0 && nviol == 0 && nneg == 0) break;
                     if (nviol == 0 && nneg == 0) {
                         ok = true;
 #pragma unroll

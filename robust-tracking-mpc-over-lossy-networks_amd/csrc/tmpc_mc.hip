@@ -1,0 +1,156 @@
+// Device-resident closed loop around the solve kernels: the body of the reference's Monte-Carlo loop
+// (Results/results_linear_system.py:209-259 and results_linear_system_with_extendedMPC.py:247-378)
+// as per-trajectory state machines, one thread per trajectory, launched once per time step right
+// after the QP solve on the same stream.  Nothing returns to the host between the steps.
+//
+// What one thread does for its trajectory at time t, in the reference's order:
+//   controller packet  U_t = [u_nom | u_bar + K x_bar]                    (TubeTrackingMPC.py:211-227)
+//   theta_t            packet controller -> plant lost?                    (results_linear_system.py:218-221)
+//   consistent actuator: Theta_t, s_t, buffer, x_nom_0 adoption, u_t       (SmartActuator.py:57-107,146-231)
+//   statistics: tracking error, x_t - x_nom_t in Z                         (results_linear_system.py:258,291)
+//   plant              x+ = A x + B u + w                                  (:248)
+//   gamma_t            packet plant -> controller lost?                    (:223-226)
+//   estimator / robust estimator update, q_t                               (Estimator.py:43-98,113-156)
+// The estimator's "sequence sent at time s_t" is, by construction, the sequence the actuator
+// buffered at time s_t, so the simulated pair shares one buffer instead of the reference's growing list.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "tmpc_device.hpp"
+
+namespace tmpc {
+
+namespace {
+
+constexpr int MAXN = 16;      // nx, nu <= 16 (tmpc_create enforces nx <= 16; nu checked by the launcher)
+
+__global__ void mc_pre_kernel(const McModel m, const McState st, const int t, const int64_t B, const double ref_t) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int i = 0; i < m.nx; ++i) st.ref_k[b * m.nx + i] = (i == 0) ? ref_t : 0.0;     // ref = [ref_t, 0, ..] (:240)
+}
+
+__global__ void mc_post_kernel(const McModel m, const McState st, const int t, const int T, const int64_t B, const double ref_t,
+                               const double *__restrict__ u_nom, const double *__restrict__ x_nom0,
+                               const double *__restrict__ xu_ss, const int32_t *__restrict__ status) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int nx = m.nx, nu = m.nu, N = m.N;
+    const double p = st.p_loss[b];
+    int theta = (t > 0 && st.th_u[b * T + t] < p) ? 0 : 1;                               // strict <, first packet always arrives
+    const int stat = status[b];
+    const bool bad = stat >= 2;
+    if (stat != 0) st.not_optimal[b] += 1;
+    if (bad) theta = 0;            // a failed solve sends nothing (the reference's tube branch would raise here)
+
+    double x[MAXN], xn[MAXN], e[MAXN];
+    for (int i = 0; i < nx; ++i) x[i] = st.x[b * nx + i];
+    if (!bad) {
+        for (int j = 0; j < nu; ++j) st.u_latest0[b * nu + j] = u_nom[b * N * nu + j];
+        for (int i = 0; i < nx; ++i) st.x_nom0_latest[b * nx + i] = x_nom0[b * nx + i];
+    }
+    // ---- consistent actuator (SmartActuator.py:57-107, 174-231)
+    if (theta == 0) st.last_lost[b] = t;
+    if (theta == 1) st.q_act[b] = st.q_est[b];
+    const int Theta = (theta == 1 && st.last_lost[b] <= st.q_act[b]) ? 1 : 0;
+    st.Theta[b] = Theta;
+    double *Ub = st.Ubuf + b * (N + 1) * nu;                  // [i][j], i = 0..N
+    if (Theta) {
+        st.s[b] = t;
+        for (int i = 0; i < N * nu; ++i) Ub[i] = u_nom[b * N * nu + i];
+        for (int j = 0; j < nu; ++j) {                         // u_bar + K x_bar (TubeTrackingMPC.py:217)
+            double v = xu_ss[b * (nx + nu) + nx + j];
+            for (int i = 0; i < nx; ++i) v += m.K[j * nx + i] * xu_ss[b * (nx + nu) + i];
+            Ub[N * nu + j] = v;
+        }
+        if (m.extended)
+            for (int i = 0; i < nx; ++i) st.x_nom[b * nx + i] = x_nom0[b * nx + i];
+    }
+    for (int i = 0; i < nx; ++i) { xn[i] = st.x_nom[b * nx + i]; e[i] = x[i] - xn[i]; }
+    const int d = t - st.s[b];
+    const bool inside = d < N;
+    double un[MAXN], u[MAXN];
+    for (int j = 0; j < nu; ++j) {
+        double v = Ub[(inside ? d : N) * nu + j];
+        if (!inside)
+            for (int i = 0; i < nx; ++i) v -= m.K[j * nx + i] * xn[i];
+        un[j] = v;
+        double w2 = v;
+        for (int i = 0; i < nx; ++i) w2 -= m.K_anc[j * nx + i] * e[i];
+        u[j] = w2;
+    }
+    // ---- statistics (results_linear_system.py:258, 291)
+    {
+        double a = (x[0] - ref_t) * (x[0] - ref_t);
+        for (int i = 1; i < nx; ++i) a += x[i] * x[i];
+        st.err2[b] += a;
+        bool out = false;
+        for (int r = 0; r < m.rZ; ++r) {
+            double v = -m.hZ[r];
+            for (int i = 0; i < nx; ++i) v += m.HZ[r * nx + i] * e[i];
+            out = out || (v > 1e-7);                            // polytope's abs_tol
+        }
+        if (out) st.tube_viol[b] += 1;
+    }
+    // ---- plant and nominal model
+    double xp[MAXN], xnp[MAXN];
+    for (int i = 0; i < nx; ++i) {
+        double v = st.w[(b * T + t) * nx + i], vn = 0.0;
+        for (int k = 0; k < nx; ++k) { v += m.A[i * nx + k] * x[k]; vn += m.A[i * nx + k] * xn[k]; }
+        for (int j = 0; j < nu; ++j) { v += m.B[i * nu + j] * u[j]; vn += m.B[i * nu + j] * un[j]; }
+        xp[i] = v;
+        xnp[i] = vn;
+    }
+    for (int i = 0; i < nx; ++i) { st.x[b * nx + i] = xp[i]; st.x_nom[b * nx + i] = xnp[i]; }
+    // ---- estimator (Estimator.py:43-98; robust: :113-156)
+    const int gamma = (t > 0 && st.ga_u[b * T + t] < p) ? 0 : 1;
+    double xh[MAXN];
+    if (gamma) {
+        // packet {'x_t', 's_t'[, 'x_nom_t']}: x_t = nominal state (consistent actuator) or plant state (extended)
+        const double *xpk = m.extended ? x : xn;
+        const double *ue = m.extended ? u : un;               // u_hat(k|k): the input the plant applied / its nominal part
+        for (int i = 0; i < nx; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < nx; ++k) v += m.A[i * nx + k] * xpk[k];
+            for (int j = 0; j < nu; ++j) v += m.B[i * nu + j] * ue[j];
+            xh[i] = v;
+        }
+        st.q_est[b] = t;
+    } else {
+        const double *base = m.extended ? st.x_nom0_latest + b * nx : st.x_hat + b * nx;
+        double bs[MAXN];
+        for (int i = 0; i < nx; ++i) bs[i] = base[i];
+        for (int i = 0; i < nx; ++i) {
+            double v = 0.0;
+            for (int k = 0; k < nx; ++k) v += m.A[i * nx + k] * bs[k];
+            for (int j = 0; j < nu; ++j) v += m.B[i * nu + j] * st.u_latest0[b * nu + j];
+            xh[i] = v;
+        }
+    }
+    double ce = 0.0;
+    for (int i = 0; i < nx; ++i) { st.x_hat[b * nx + i] = xh[i]; ce = fmax(ce, fabs(xh[i] - xnp[i])); }
+    if (Theta && gamma && !m.extended) st.consistent[b] = fmax(st.consistent[b], ce);     // Proposition 1
+    st.gamma[b] = static_cast<uint8_t>(gamma);
+}
+
+}  // namespace
+
+hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream) {
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((B + threads - 1) / threads);
+    hipLaunchKernelGGL(mc_pre_kernel, dim3(blocks), dim3(threads), 0, stream, m, st, t, B, ref_t);
+    return hipGetLastError();
+}
+
+hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
+                          const double *x_nom0, const double *xu_ss, const int32_t *status, hipStream_t stream) {
+    if (m.nx > MAXN || m.nu > MAXN) return hipErrorInvalidValue;
+    const int threads = 64;
+    const unsigned blocks = static_cast<unsigned>((B + threads - 1) / threads);
+    hipLaunchKernelGGL(mc_post_kernel, dim3(blocks), dim3(threads), 0, stream, m, st, t, T, B, ref_t, u_nom, x_nom0, xu_ss, status);
+    return hipGetLastError();
+}
+
+}  // namespace tmpc

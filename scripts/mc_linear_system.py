@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--N", type=int, default=20)               # :64
     ap.add_argument("--ref", type=float, default=0.5)          # :160
     ap.add_argument("--extended", action="store_true")
+    ap.add_argument("--host-loop", action="store_true", help="state machines in numpy on the host instead of on the device")
     args = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     import torch
@@ -38,7 +39,7 @@ def main():
     p_loss = np.arange(10) / 10.0                              # :149
     t0 = time.time()
     table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
-                                    extended=args.extended, device=device)
+                                    extended=args.extended, device=device, on_device=not args.host_loop)
     dt = time.time() - t0
     if rank == 0:
         n = len(pi)
