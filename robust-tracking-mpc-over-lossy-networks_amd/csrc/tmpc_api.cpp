@@ -207,6 +207,15 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload(h, v, GH.data(), GH.size(), &v.bq.GHrm))) return rc;
     if ((rc = upload(h, v, g0.data(), g0.size(), &v.bq.g0))) return rc;
     if ((rc = upload(h, v, Es.data(), Es.size(), &v.bq.Es))) return rc;
+#ifdef TMPC_STAMPS
+    {
+        void *dbgp = nullptr;
+        HIP_TRY(h, hipMalloc(&dbgp, 16 * sizeof(long long)));
+        HIP_TRY(h, hipMemset(dbgp, 0, 16 * sizeof(long long)));
+        v.dev.push_back(dbgp);
+        v.db.dbg = static_cast<long long *>(dbgp);
+    }
+#endif
     return TMPC_OK;
 }
 
@@ -593,7 +602,8 @@ int tmpc_kernel_ms_total(tmpc_handle *h, float *total_ms, int32_t *launches, int
 int tmpc_debug_stamps(tmpc_handle *h, int variant, long long *out12) {
     if (!h || !out12) return TMPC_E_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
-    HIP_TRY(h, hipMemcpy(out12, h->v[variant].d.dbg, 12 * sizeof(long long), hipMemcpyDeviceToHost));
+    const long long *src = use_block(h, h->v[variant]) ? h->v[variant].db.dbg : h->v[variant].d.dbg;
+    HIP_TRY(h, hipMemcpy(out12, src, 12 * sizeof(long long), hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
 #endif

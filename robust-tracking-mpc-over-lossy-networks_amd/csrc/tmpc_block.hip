@@ -82,16 +82,20 @@ __device__ __forceinline__ double block_reduce1(double a, double *red, int wave,
     return Op::f(Op::f(red[0], red[1]), Op::f(red[2], red[3]));
 }
 
-// G_row(r) . v for the thread's row: column-major copy, v in LDS (broadcast reads)
+// G_row(r) . v for the thread's row: column-major copy, v in LDS (broadcast reads).  Eight loads in flight per
+// step: the operands come from L2, the loop is bound by how many of them are outstanding.
 __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v) {
-    double t0 = 0.0, t1 = 0.0;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     int j = 0;
-    for (; j + 1 < nv; j += 2) {
-        t0 = fma(Gcm[static_cast<size_t>(j) * ncp + r], v[j], t0);
-        t1 = fma(Gcm[static_cast<size_t>(j + 1) * ncp + r], v[j + 1], t1);
+    for (; j + 8 <= nv; j += 8) {
+        double g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = Gcm[static_cast<size_t>(j + k) * ncp + r];
+        t0 = fma(g[0], v[j], t0); t1 = fma(g[1], v[j + 1], t1); t2 = fma(g[2], v[j + 2], t2); t3 = fma(g[3], v[j + 3], t3);
+        t0 = fma(g[4], v[j + 4], t0); t1 = fma(g[5], v[j + 5], t1); t2 = fma(g[6], v[j + 6], t2); t3 = fma(g[7], v[j + 7], t3);
     }
-    if (j < nv) t0 = fma(Gcm[static_cast<size_t>(j) * ncp + r], v[j], t0);
-    return t0 + t1;
+    for (; j < nv; ++j) t0 = fma(Gcm[static_cast<size_t>(j) * ncp + r], v[j], t0);
+    return (t0 + t1) + (t2 + t3);
 }
 
 // out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
@@ -102,12 +106,21 @@ __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int 
     const int j = tid % NVP, part = tid / NVP;
     double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
     int r = part;
-    for (; r + PARTS < nc; r += 2 * PARTS) {
-        const double g0 = Grm[static_cast<size_t>(r) * NVP + j], g1 = Grm[static_cast<size_t>(r + PARTS) * NVP + j];
-        a0 = fma(g0, va[r], a0); b0 = fma(g0, vb[r], b0);
-        a1 = fma(g1, va[r + PARTS], a1); b1 = fma(g1, vb[r + PARTS], b1);
+    for (; r + 7 * PARTS < nc; r += 8 * PARTS) {           // eight rows in flight (L2 latency, see row_dot)
+        double g[8], xa[8], xb[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            g[k] = Grm[static_cast<size_t>(r + k * PARTS) * NVP + j];
+            xa[k] = va[r + k * PARTS];
+            xb[k] = vb[r + k * PARTS];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            a0 = fma(g[k], xa[k], a0); b0 = fma(g[k], xb[k], b0);
+            a1 = fma(g[k + 1], xa[k + 1], a1); b1 = fma(g[k + 1], xb[k + 1], b1);
+        }
     }
-    if (r < nc) {
+    for (; r < nc; r += PARTS) {
         const double g0 = Grm[static_cast<size_t>(r) * NVP + j];
         a0 = fma(g0, va[r], a0); b0 = fma(g0, vb[r], b0);
     }
@@ -141,34 +154,43 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
 #pragma unroll
     for (int t = 0; t < NB; ++t) accB[t] = v4d{0.0, 0.0, 0.0, 0.0};
     const int kq = lane >> 4, c = lane & 15;
-    double cur[NB], nxt[NB];
-    double dcur = 0.0, dnxt = 0.0;
+    // U k-steps per group, the next group's operands in flight while the current group's MFMAs run:
+    // the loads come from L2 (~1-2 k cycles away), one k-step of look-ahead would leave the matrix core idle
+    constexpr int U = T >= 4 ? 2 : 4;
+    double cur[U][NB], nxt[U][NB];
+    double dcur[U], dnxt[U];
+    auto load_group = [&](int ks0, double (&g)[U][NB], double (&dv)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = ks0 + u * RS;
+            const bool in = ks < nsteps;
+            const size_t row = static_cast<size_t>(4 * (in ? ks : 0) + kq);
+#pragma unroll
+            for (int t = 0; t < NB; ++t) g[u][t] = Grm[row * NVP + 16 * t + c];
+            dv[u] = in ? dvec[row] : 0.0;
+        }
+    };
     int ks = rpart;
-    if (ks < nsteps) {
-        const size_t row = static_cast<size_t>(4 * ks + kq);
+    load_group(ks, cur, dcur);                  // unconditional (indices are clamped inside): a branch around the
+    for (; ks < nsteps; ks += RS * U) {         // prefetch makes the compiler wait for ALL loads before the MFMAs
+        load_group(ks + RS * U, nxt, dnxt);
 #pragma unroll
-        for (int t = 0; t < NB; ++t) cur[t] = Grm[row * NVP + 16 * t + c];
-        dcur = dvec[row];
-    }
-    for (; ks < nsteps; ks += RS) {
-        const int kn = ks + RS;
-        if (kn < nsteps) {
-            const size_t row = static_cast<size_t>(4 * kn + kq);
+        for (int u = 0; u < U; ++u) {
+            const double aB = dcur[u] * cur[u][RB];
 #pragma unroll
-            for (int t = 0; t < NB; ++t) nxt[t] = Grm[row * NVP + 16 * t + c];
-            dnxt = dvec[row];
-        }
-        const double aB = dcur * cur[RB];
+            for (int t = 0; t < NB; ++t) accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, cur[u][t], accB[t], 0, 0, 0);
+            if constexpr (NA > 0) {
+                const double aA = dcur[u] * cur[u][RA];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, cur[t], accB[t], 0, 0, 0);
-        if constexpr (NA > 0) {
-            const double aA = dcur * cur[RA];
-#pragma unroll
-            for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, cur[t], accA[t], 0, 0, 0);
+                for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, cur[u][t], accA[t], 0, 0, 0);
+            }
         }
 #pragma unroll
-        for (int t = 0; t < NB; ++t) cur[t] = nxt[t];
-        dcur = dnxt;
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int t = 0; t < NB; ++t) cur[u][t] = nxt[u][t];
+            dcur[u] = dnxt[u];
+        }
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
@@ -253,6 +275,13 @@ __device__ __forceinline__ void wave_llt_solve(const double *L, int ld, int n, c
     if (i1 < n) x[i1] = b1; else if (i1 < nfill) x[i1] = 0.0;
 }
 
+// Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of workgroup 0, written to qp.dbg
+#ifdef TMPC_STAMPS
+#define BSTAMP(p) do { __syncthreads(); long long now_ = __builtin_amdgcn_s_memtime(); tph[p] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define BSTAMP(p) do { } while (0)
+#endif
+
 template <int T>
 __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
     const DeviceQP qp, const BlockQP bq, double *__restrict__ ws, const int variant_id, const int64_t B,
@@ -304,6 +333,10 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
         __syncthreads();
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
+#ifdef TMPC_STAMPS
+        long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long tlast = __builtin_amdgcn_s_memtime();
+#endif
 
         int bad = qp.always_infeasible != 0;
         for (int r = tid; r < qp.npar; r += BT) {
@@ -348,6 +381,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
         }
         block_reduce3<OpMax, OpMax, OpMin>(qn_l, hn_l, smin_l, red, wave, lane);
         const double qn = qn_l, hn = hn_l, smin = smin_l;
+        BSTAMP(0);
 
         if (bad) {
             st = TMPC_STATUS_INFEASIBLE;
@@ -388,6 +422,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     }
                     block_reduce3<OpSum, OpMax, OpMax>(gap, rpn, lmax, red, wave, lane);
                     const double mu = gap / ncd;
+                    BSTAMP(1);
                     // ---- P2: cost gradient, G'lam, G'(d.rp)
                     if (tid < NVP) {
                         double v = qv[tid];
@@ -405,6 +440,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         rhsv[tid] = -cgj - tv[tid];
                     }
                     block_reduce3<OpMax, OpSum, OpMax>(rdn, obj, gln, red, wave, lane);
+                    BSTAMP(2);
                     if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
                     const double objs = fmax(fabs(obj), 1.0);
                     const bool try_polish = (rdn <= 1e3 * try_tol * qn) && (rpn <= try_tol * hn) && (gap <= try_tol * objs);
@@ -426,8 +462,11 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             big[i * LDM + j] = qp.Hs[idx] + (i == j ? shift : 0.0);
                         }
                         __syncthreads();
+                        BSTAMP(3);
                         gdg_all<T>(Grm, d_, nsteps, big, wave, lane);
+                        BSTAMP(4);
                         spd = block_chol(big, LDM, nv, dinv, tid);
+                        BSTAMP(5);
                         if (!spd) {
                             double trc = 0.0;
                             for (int i = 0; i < nv; ++i) trc += qp.Hs[i * NVP + i];
@@ -437,6 +476,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
                     if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, rhsv, dzav, lane, NVP);
                     __syncthreads();
+                    BSTAMP(6);
                     // ---- P5: affine step statistics, corrector terms per row
                     double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
                     for (int r = tid; r < ncp; r += BT) {
@@ -461,12 +501,14 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     double sigma = mu_aff / mu;
                     sigma = fmin(sigma * sigma * sigma, 1.0);
                     const double smu = sigma * mu;
+                    BSTAMP(7);
                     // ---- P6: corrector right-hand side and solve
                     gt_products<T>(Grm, nc, c1_, rs_, parts, tv, uv, tid);
                     if (tid < NVP) cgv[tid] = rhsv[tid] + tv[tid] - smu * uv[tid];
                     __syncthreads();
                     if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, cgv, dzv, lane, NVP);
                     __syncthreads();
+                    BSTAMP(8);
                     // ---- P7: final direction per row, step length
                     double om = (1.0 - aaff) * (1.0 - aaff);
                     om = fmin(fmax(om, 1e-4), 1e-2);
@@ -496,6 +538,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     if (tid < NVP) zv[tid] += alpha * dzv[tid];
                     __syncthreads();
                     it_done = it + 1;
+                    BSTAMP(9);
                 }
                 if (!want_polish) break;
                 // ------------------------------------------------ active-set refinement
@@ -629,6 +672,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         }
                     }
                 }
+                BSTAMP(10);
                 if (ok) { st = TMPC_STATUS_OPTIMAL; break; }
                 if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
                 try_tol *= 1e-2;
@@ -674,6 +718,10 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
             }
         }
         if (tid == 0) { status[b] = st; iters[b] = it_done; }
+#ifdef TMPC_STAMPS
+        BSTAMP(11);
+        if (b == 0 && tid == 0 && qp.dbg) { for (int p_ = 0; p_ < 12; ++p_) qp.dbg[p_] = tph[p_]; }
+#endif
     }
 }
 

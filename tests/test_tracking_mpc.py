@@ -1,0 +1,59 @@
+"""R-MPC comparator (reference TrackingMPC.py) on the device kernels."""
+import numpy as np
+import pytest
+
+import common
+from LinearMPCOverNetworks import workloads
+from LinearMPCOverNetworks.TrackingMPC import TrackingMPC
+from oracle.oracle import Oracle
+
+
+def _make(create):
+    w = workloads.double_integrator()
+    mpc = TrackingMPC(w["A"], w["B"], w["Q"], w["R"], 10)
+    mpc.set_input_constraints(w["U"])
+    mpc.set_state_constraints(w["X"])
+    mpc._Xc, mpc._Uc = mpc._X, mpc._U
+    mpc.determine_Xf(verbose=False)
+    mpc._fixed_initial_state = True
+    if create:
+        mpc.generate_optimization_problem()
+    return mpc, w
+
+
+def test_problem_is_the_untightened_fixed_x0_qp(oracle_lib):
+    mpc, w = _make(False)
+    p = mpc._problem_dict()
+    assert p["fixed_x0"] == 1 and "HZ" not in p
+    assert np.array_equal(p["Hx"], w["X"].A) and np.array_equal(p["hu"], w["U"].b)       # TrackingMPC.py:94-97
+    orc = Oracle(p)
+    sol = orc.solve(np.array([[1.0, 2.0], [7.9, 0.9]]), np.array([[5.0, 0.0], [5.0, 0.0]]))
+    assert sol["status"][0] == 0
+    # x = (7.9, 0.9): the next state 8.8 leaves X whatever the bounded input does -> infeasible (U_t = None in the reference)
+    assert sol["status"][1] == 2
+    # terminal-set requirement of this implementation
+    bare = TrackingMPC(w["A"], w["B"], w["Q"], w["R"], 10)
+    with pytest.raises(NotImplementedError):
+        bare.generate_optimization_problem()
+
+
+@pytest.mark.gpu
+def test_tracking_mpc_parity_and_packets(hip_lib, oracle_lib):
+    mpc, w = _make(True)
+    orc = Oracle(mpc._problem_dict())
+    rng = np.random.default_rng(5)
+    X = rng.uniform(-1, 1, (128, 2)) * [6.0, 1.0]
+    R = np.c_[rng.uniform(-7, 7, 128), np.zeros(128)]
+    ref = orc.solve(X, R)
+    x_mpc, u_mpc, x_bar, u_bar = mpc.solve_optimization_problem(X, R)
+    assert np.array_equal(mpc.last_status, ref["status"])
+    ok = ref["status"] == 0
+    assert 40 < ok.sum() and (~ok).sum() > 0
+    np.testing.assert_allclose(u_mpc[ok], ref["u_nom"][ok], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(x_bar[ok], ref["x_ss"][ok], atol=1e-9, rtol=0)
+    i, j = int(np.flatnonzero(ok)[0]), int(np.flatnonzero(~ok)[0])
+    pkt = mpc.determine_packet(X[i].copy(), R[i].copy(), 3)
+    assert pkt["U_t"].shape == (1, 11) and pkt["q_t"] == 3
+    np.testing.assert_allclose(pkt["U_t"][0, :10], ref["u_nom"][i, :, 0], atol=1e-8)
+    np.testing.assert_allclose(pkt["U_t"][0, 10], ref["u_ss"][i, 0] + (mpc._K @ ref["x_ss"][i])[0], atol=1e-8)
+    assert mpc.determine_packet(X[j].copy(), R[j].copy(), 4)["U_t"] is None                 # infeasible -> None (results_linear_system.py:268)
