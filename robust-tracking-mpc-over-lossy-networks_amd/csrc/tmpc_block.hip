@@ -229,47 +229,110 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
     }
 }
 
-// Right-looking Cholesky of the n x n lower triangle at Mx (LDS, row stride ld) by the whole
-// workgroup.  The diagonal is left untouched; dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a
-// non-positive pivot.
-__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, int tid) {
+// Right-looking Cholesky of the n x n lower triangle at Mx (LDS, row stride ld) by the whole workgroup, with the
+// matrix held in REGISTERS: thread (tx, ty) = (tid & 15, tid >> 4) owns the elements (ty + 16 a, tx + 16 b), a >= b
+// (NB (NB+1) / 2 values for n <= 16 NB).  Per column: the owner publishes the pivot, the owners of the column scale it
+// and write it to its final place in LDS, then every thread updates its own elements with two short LDS reads per
+// element row/column -- no read-modify-write chains through LDS.  On return the strictly lower triangle of Mx holds L,
+// dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a non-positive pivot.
+template <int NB>
+__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid) {
     const int tx = tid & 15, ty = tid >> 4;
-    for (int j = 0; j < n; ++j) {
-        __syncthreads();
-        const double pjj = Mx[j * ld + j];
-        if (!(pjj > 0.0)) return false;
-        const double inv = 1.0 / sqrt(pjj);
-        const int n1 = n - j - 1;
-        for (int i = tid; i < n1; i += BT) Mx[(j + 1 + i) * ld + j] *= inv;
-        if (tid == 0) dinv[j] = inv;
-        __syncthreads();
-        for (int ri = ty; ri < n1; ri += 16) {
-            const double lij = Mx[(j + 1 + ri) * ld + j];
-            for (int ck = tx; ck <= ri; ck += 16) Mx[(j + 1 + ri) * ld + j + 1 + ck] -= lij * Mx[(j + 1 + ck) * ld + j];
+    double m[NB][NB];
+#pragma unroll
+    for (int a = 0; a < NB; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            const int r = ty + 16 * a, c = tx + 16 * b;
+            m[a][b] = (r < n && c <= r) ? Mx[r * ld + c] : 0.0;
+        }
+    bool ok = true;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        if (16 * jb >= n || !ok) break;
+        for (int jl = 0; jl < 16; ++jl) {
+            const int j = 16 * jb + jl;
+            if (j >= n) break;
+            if (ty == jl && tx == jl) piv[0] = m[jb][jb];
+            __syncthreads();
+            const double pjj = piv[0];
+            if (!(pjj > 0.0)) { ok = false; break; }
+            const double inv = 1.0 / sqrt(pjj);
+            if (tx == jl) {
+#pragma unroll
+                for (int a = jb; a < NB; ++a) {
+                    const int r = ty + 16 * a;
+                    if (r > j && r < n) { m[a][jb] *= inv; Mx[r * ld + j] = m[a][jb]; }
+                }
+            }
+            if (tid == 0) dinv[j] = inv;
+            __syncthreads();
+            double lr[NB], lc[NB];
+#pragma unroll
+            for (int a = jb; a < NB; ++a) {
+                const int r = ty + 16 * a, c = tx + 16 * a;
+                lr[a] = (r > j && r < n) ? Mx[r * ld + j] : 0.0;
+                lc[a] = (c > j && c < n) ? Mx[c * ld + j] : 0.0;
+            }
+#pragma unroll
+            for (int a = jb; a < NB; ++a)
+#pragma unroll
+                for (int b = jb; b <= a; ++b) m[a][b] = fma(-lr[a], lc[b], m[a][b]);
         }
     }
     __syncthreads();
-    return true;
+    return ok;
 }
 
-// L L' x = b in one wave (n <= 128): lane l holds entries l and l + 64.  b and x may alias.
+// L L' x = b in one wave (n <= 128): lane l holds entries l and l + 64.  b and x may alias.  The entries of L and
+// the reciprocal pivots of eight columns are fetched ahead of the eight dependent steps that use them, so that the
+// chain per step is readlane - multiply - fma and not an LDS round trip.
 __device__ __forceinline__ void wave_llt_solve(const double *L, int ld, int n, const double *dinv, const double *b, double *x, int lane,
                                                int nfill = 0) {
     const int i0 = lane, i1 = lane + WAVE;
+    const int r0 = i0 < n ? i0 : 0, r1 = i1 < n ? i1 : 0;
     double b0 = i0 < n ? b[i0] : 0.0, b1 = i1 < n ? b[i1] : 0.0;
-    for (int j = 0; j < n; ++j) {
-        const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
-        const double yj = bj * dinv[j];
-        if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = yj; else b1 = yj; }
-        if (i0 > j && i0 < n) b0 = fma(-L[i0 * ld + j], yj, b0);
-        if (i1 > j && i1 < n) b1 = fma(-L[i1 * ld + j], yj, b1);
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        double l0[8], l1[8], di[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = (j0 + k < n) ? j0 + k : n - 1;
+            di[k] = dinv[j];
+            l0[k] = L[r0 * ld + j];
+            l1[k] = L[r1 * ld + j];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = j0 + k;
+            if (j < n) {
+                const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
+                const double yj = bj * di[k];
+                if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = yj; else b1 = yj; }
+                if (i0 > j && i0 < n) b0 = fma(-l0[k], yj, b0);
+                if (i1 > j && i1 < n) b1 = fma(-l1[k], yj, b1);
+            }
+        }
     }
-    for (int j = n - 1; j >= 0; --j) {
-        const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
-        const double xj = bj * dinv[j];
-        if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = xj; else b1 = xj; }
-        if (i0 < j) b0 = fma(-L[j * ld + i0], xj, b0);
-        if (i1 < j) b1 = fma(-L[j * ld + i1], xj, b1);
+    for (int j0 = ((n - 1) / 8) * 8; j0 >= 0; j0 -= 8) {
+        double l0[8], l1[8], di[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int j = (j0 + k < n) ? j0 + k : n - 1;
+            di[k] = dinv[j];
+            l0[k] = L[j * ld + r0];
+            l1[k] = L[j * ld + r1];
+        }
+#pragma unroll
+        for (int k = 7; k >= 0; --k) {
+            const int j = j0 + k;
+            if (j < n) {
+                const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
+                const double xj = bj * di[k];
+                if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = xj; else b1 = xj; }
+                if (i0 < j) b0 = fma(-l0[k], xj, b0);
+                if (i1 < j) b1 = fma(-l1[k], xj, b1);
+            }
+        }
     }
     if (i0 < n) x[i0] = b0; else if (i0 < nfill) x[i0] = 0.0;      // entries n..nfill-1 (padding) are cleared
     if (i1 < n) x[i1] = b1; else if (i1 < nfill) x[i1] = 0.0;
@@ -465,7 +528,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         BSTAMP(3);
                         gdg_all<T>(Grm, d_, nsteps, big, wave, lane);
                         BSTAMP(4);
-                        spd = block_chol(big, LDM, nv, dinv, tid);
+                        spd = block_chol<T>(big, LDM, nv, dinv, red + 16, tid);
                         BSTAMP(5);
                         if (!spd) {
                             double trc = 0.0;
@@ -592,7 +655,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             double dmax = (tid < m) ? S[tid * LDSS + tid] : 0.0;
                             dmax = block_reduce1<OpMax>(dmax, red, wave, lane);
                             if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
-                            if (!block_chol(S, LDSS, m, dinv, tid)) break;
+                            if (!block_chol<(WCAP + 15) / 16>(S, LDSS, m, dinv, red + 16, tid)) break;
                             for (int stp = 0; stp < 4; ++stp) {
                                 // r1 = Hs zp + q + G_W' y
                                 if (tid < NVP) {
