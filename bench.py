@@ -62,6 +62,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="QP instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop extra (profiling runs: keeps the kernel statistics to the timed steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,7 +169,7 @@ def main():
                        "mean_ipm_iters": float(iters_all.mean()), "optimal_fraction": float((status_all == 0).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "tmpc::solve_kernel<12,8>", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": "tmpc::solve_kernel<12,2,6,7,false,4>", "avg_kernel_ms": avg_kernel_s * 1e3,
                          "flops_per_launch": flops_launch,
                          "note": "bound is FP64 arithmetic (vector ALU; 78.6 TFLOP/s is also the FP64 MFMA peak), "
                                  "not HBM: algorithmic HBM bytes are %d B/solve" % bytes_solve,
@@ -179,7 +180,7 @@ def main():
             from oracle.oracle import Oracle
             orc = Oracle(mpc._problem_dict())
             cores = host_cores()
-            ns = 16384
+            ns = 131072
             ii = np.random.default_rng(5).integers(0, len(S), ns)
             Xc, Rc = S[ii, :nx].copy(), S[ii, nx:].copy()
             orc.solve(Xc[:256], Rc[:256], nthreads=cores)
@@ -189,6 +190,19 @@ def main():
             out["cpu_baseline"] = {"value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
                                    "sample": f"{ns} instances of the same workload, oracle/tmpc_oracle.c (IPM + refinement), "
                                              f"OpenMP over the batch, {tc:.2f} s wall, mean iters {oc['iters'].mean():.2f}"}
+        if world == 1 and not args.no_closed_loop:
+            # the same kernel inside the device-resident closed loop over the lossy network (tmpc_mc_run): every step is
+            # the solve + the estimator / actuator / plant state machines, 4096 trajectories, p_loss = 0.3 (configs[1])
+            Tcl = 50
+            th, ga, wd = montecarlo.draw_realisations(B, Tcl, w["w_bound"], seed=99)
+            pl = np.full(B, 0.3)
+            mpc.run_closed_loop(pl[:64], 0.5 * np.ones(Tcl), th[:64], ga[:64], wd[:64])          # warm-up
+            tcl = time.perf_counter()
+            cl = mpc.run_closed_loop(pl, 0.5 * np.ones(Tcl), th, ga, wd)
+            tcl = time.perf_counter() - tcl
+            out["closed_loop"] = {"value": B * Tcl / tcl, "unit": "MPC steps/s", "trajectories": B, "steps": Tcl, "p_loss": 0.3,
+                                  "tube_violations": int(cl["tube_violations"].sum()), "non_optimal_solves": int(cl["not_optimal"].sum()),
+                                  "note": "end to end incl. upload of the realisations and download of the statistics"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
