@@ -300,7 +300,7 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
                                               double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
     constexpr int NV = SH::NV, NDP = SH::NDP, NT = SH::NT;
     constexpr int TRI = col_off<NV>(J1) - col_off<NV>(J0);
-    constexpr int CNT = TRI + (FIRST ? 2 * NV : 0);
+    constexpr int CNT = TRI + (FIRST ? NV : 0);
     constexpr int I0 = FIRST ? 0 : J0;        // first column this sweep has to load
     double acc[CNT];
 #pragma unroll
@@ -325,10 +325,7 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
             rpn_l = fmax(rpn_l, fabs(rpk));
             const double t = d * rpk;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                acc[TRI + i] += g[i] * t;
-                acc[TRI + NV + i] += g[i] * lam[k];
-            }
+            for (int i = 0; i < NV; ++i) acc[TRI + i] += g[i] * t;
         }
 #pragma unroll
         for (int j = J0; j < J1; ++j) {
@@ -339,14 +336,14 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
         row_fence();
     }
     if (FIRST) {
-        // triangle block -> its packed position; the two vectors -> behind the triangle
-        double tri[TRI > 0 ? TRI : 1], vecs[2 * NV];
+        // triangle block -> its packed position; G'(d.rp) -> behind the triangle
+        double tri[TRI > 0 ? TRI : 1], vecs[NV];
 #pragma unroll
         for (int i = 0; i < TRI; ++i) tri[i] = acc[i];
 #pragma unroll
-        for (int i = 0; i < 2 * NV; ++i) vecs[i] = acc[TRI + i];
+        for (int i = 0; i < NV; ++i) vecs[i] = acc[TRI + i];
         if constexpr (TRI > 0) wave_reduce_to_lds<TRI>(tri, red, sums + col_off<NV>(J0), lane);
-        wave_reduce_to_lds<2 * NV>(vecs, red, sums + NT, lane);
+        wave_reduce_to_lds<NV>(vecs, red, sums + NT, lane);
     } else {
         wave_reduce_to_lds<CNT>(acc, red, sums + col_off<NV>(J0), lane);
     }
@@ -370,9 +367,9 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                                  double &gap_l, double &rpn_l, double *red, double *csums, int lane, int ncc) {
     constexpr int KC = SH::KC, KT = SH::KT, NCCP = SH::NCCP;
-    double acc[KT + 2 * KC];
+    double acc[KT + KC];
 #pragma unroll
-    for (int i = 0; i < KT + 2 * KC; ++i) acc[i] = 0.0;
+    for (int i = 0; i < KT + KC; ++i) acc[i] = 0.0;
 #pragma unroll
     for (int k = SH::RD; k < SH::RT; ++k) {
         const int rc = lane + (k - SH::RD) * WAVE;
@@ -393,10 +390,9 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
 #pragma unroll
             for (int b2 = a; b2 < KC; ++b2) acc[col_off<KC>(a) + b2 - a] += dg * hc[b2];
             acc[KT + a] += hc[a] * t;
-            acc[KT + KC + a] += hc[a] * lam[k];
         }
     }
-    wave_reduce_to_lds<KT + 2 * KC>(acc, red, csums, lane);
+    wave_reduce_to_lds<KT + KC>(acc, red, csums, lane);
 }
 
 // (G_row . z, G_row . d1[, G_row . d2]) for the row in (slot K, this lane), sharing the row's loads
@@ -621,15 +617,14 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         }
                         Pm[idx] = v;
                     }
-                    double v1 = 0.0, gl = 0.0;
+                    double v1 = 0.0;
                     if (lane < NV) {
                         v1 = (RD > 0) ? sums[NT + lane] : 0.0;
-                        gl = (RD > 0) ? sums[NT + NV + lane] : 0.0;
 #pragma unroll
-                        for (int a = 0; a < KC; ++a) { v1 += Psi[a * NV + lane] * csums[KT + a]; gl += Psi[a * NV + lane] * csums[KT + KC + a]; }
+                        for (int a = 0; a < KC; ++a) v1 += Psi[a * NV + lane] * csums[KT + a];
                     }
                     wave_lds_fence();
-                    if (lane < NV) { sums[NT + lane] = v1; sums[NT + NV + lane] = gl; }
+                    if (lane < NV) sums[NT + lane] = v1;
                     wave_lds_fence();
                 }
                 double lmax = 0.0;
@@ -648,30 +643,72 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     cgv[lane] = v + qv[lane];
                 }
                 wave_lds_fence();
-                double rdn = 0.0, obj = 0.0;
+                double obj = 0.0;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) {
                     const double cgj = cgv[j], qj = qv[j];
-                    rdn = fmax(rdn, fabs(cgj + sums[NT + NV + j]));
                     obj += zv[j] * (0.5 * (cgj - qj) + qj);
                 }
-                if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
+                if (!(mu == mu)) { st = TMPC_STATUS_NUMERICAL; break; }
                 const double objs = fmax(fabs(obj), 1.0);
                 STAMP(2);
-                const bool try_polish = (rdn <= 1e3 * try_tol * qn) && (rpn <= try_tol * hn) && (gap <= try_tol * objs);
-                if (try_polish) { want_polish = true; rdn_last = rdn; break; }
-                if (gap <= 1e-15 * objs) { st = TMPC_STATUS_MAX_ITER; break; }
-                if (lmax > 1e10) {
-                    // Farkas-type certificate: lam blows up, G'lam -> 0, h'lam < 0
-                    double hl = 0.0;
+                // The dual residual needs G'lam, which nothing else uses: it is formed (one more pass over the rows) only when
+                // the primal residual and the gap already pass, or when the multipliers blow up (Farkas test).
+                const bool near = (rpn <= try_tol * hn) && (gap <= try_tol * objs);
+                if (near || lmax > 1e10) {
+                    if constexpr (RD > 0) {
+                        double accl[NV];
 #pragma unroll
-                    for (int k = 0; k < RT; ++k) hl += hw[k * WAVE + lane] * lam[k];
-                    hl = wave_sum(hl);
-                    double gn = 0.0;
+                        for (int i = 0; i < NV; ++i) accl[i] = 0.0;
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) gn = fmax(gn, fabs(sums[NT + NV + j]));
-                    if (hl < 0.0 && gn <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
+                        for (int k = 0; k < RD; ++k) {
+                            const int r = lane + k * WAVE;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) accl[j] += Gt[j * NDP + r] * lam[k];
+                            row_fence();
+                        }
+                        wave_reduce_to_lds<NV>(accl, red, sums + NT + NV, lane);
+                    }
+                    if constexpr (KC > 0) {
+                        double accl[KC];
+#pragma unroll
+                        for (int a = 0; a < KC; ++a) accl[a] = 0.0;
+#pragma unroll
+                        for (int k = RD; k < RT; ++k) {
+                            const int rc = lane + (k - RD) * WAVE;
+#pragma unroll
+                            for (int a = 0; a < KC; ++a) accl[a] += Hct[a * NCCP + rc] * lam[k];
+                        }
+                        wave_reduce_to_lds<KC>(accl, red, csums + KT + KC, lane);
+                        double gl = 0.0;
+                        if (lane < NV) {
+                            gl = (RD > 0) ? sums[NT + NV + lane] : 0.0;
+#pragma unroll
+                            for (int a = 0; a < KC; ++a) gl += Psi[a * NV + lane] * csums[KT + KC + a];
+                        }
+                        wave_lds_fence();
+                        if (lane < NV) sums[NT + NV + lane] = gl;
+                        wave_lds_fence();
+                    }
+                    double rdn = 0.0, gn = 0.0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        const double glj = sums[NT + NV + j];
+                        rdn = fmax(rdn, fabs(cgv[j] + glj));
+                        gn = fmax(gn, fabs(glj));
+                    }
+                    if (!(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
+                    if (near && rdn <= 1e3 * try_tol * qn) { want_polish = true; rdn_last = rdn; break; }
+                    if (lmax > 1e10) {
+                        // Farkas-type certificate: lam blows up, G'lam -> 0, h'lam < 0
+                        double hl = 0.0;
+#pragma unroll
+                        for (int k = 0; k < RT; ++k) hl += hw[k * WAVE + lane] * lam[k];
+                        hl = wave_sum(hl);
+                        if (hl < 0.0 && gn <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
+                    }
                 }
+                if (gap <= 1e-15 * objs) { st = TMPC_STATUS_MAX_ITER; break; }
                 // ---- M = Hs + G'DG by rows (lane i holds row i), elimination with the predictor rhs carried along
                 double mrow[NV], mdinv = 1.0, rhs_i = 0.0;
                 {
