@@ -43,6 +43,7 @@ def test_tracking_mpc_parity_and_packets(hip_lib, oracle_lib):
     orc = Oracle(mpc._problem_dict())
     rng = np.random.default_rng(5)
     X = rng.uniform(-1, 1, (128, 2)) * [6.0, 1.0]
+    X[-4:] = [[7.9, 0.9], [-7.9, -0.9], [7.5, 1.0], [-7.99, -0.5]]      # the next state leaves X whatever u does
     R = np.c_[rng.uniform(-7, 7, 128), np.zeros(128)]
     ref = orc.solve(X, R)
     x_mpc, u_mpc, x_bar, u_bar = mpc.solve_optimization_problem(X, R)
