@@ -444,12 +444,20 @@ static double max_step(const double *s, const double *ds, const double *l, const
  * interior-point multipliers.  The result is accepted only if it is primal
  * feasible on all rows and y >= 0; otherwise W is corrected and the step repeated.
  * Returns 1 on success (z, lam overwritten by the exact KKT point). */
+/* developer statistics (single-threaded runs only): refinement calls / rounds / successes */
+static long g_polish_calls = 0, g_polish_rounds = 0, g_polish_ok = 0;
+void oracle_debug_counters(long *out3, int reset) {
+    if (out3) { out3[0] = g_polish_calls; out3[1] = g_polish_rounds; out3[2] = g_polish_ok; }
+    if (reset) g_polish_calls = g_polish_rounds = g_polish_ok = 0;
+}
 static int polish(const form_t *f, work_t *w) {
+    ++g_polish_calls;
     const int nv = f->nw, nc = f->nc;
     const double *Gs = f->Gs, *Hs = f->Hs, *Hinv = f->Hinv;
     for (int i = 0; i < nc; ++i) { w->inW[i] = w->lam[i] > w->s[i]; w->yall[i] = w->lam[i]; }
     memcpy(w->zp, w->z, sizeof(double) * nv);
     for (int it = 0; it < 6; ++it) {
+        ++g_polish_rounds;
         int m = 0;
         for (int i = 0; i < nc; ++i) if (w->inW[i]) { if (m >= w->wcap) return 0; w->W[m++] = i; }
         if (m == 0) {
@@ -517,6 +525,7 @@ static int polish(const form_t *f, work_t *w) {
             memcpy(w->z, w->zp, sizeof(double) * nv);
             for (int i = 0; i < nc; ++i) { w->lam[i] = 0; w->s[i] = w->r[i] < 0 ? -w->r[i] : 0; }
             for (int k = 0; k < m; ++k) w->lam[w->W[k]] = w->y[k] > 0 ? w->y[k] : 0;
+            ++g_polish_ok;
             return 1;
         }
         for (int k = 0; k < m; ++k) w->yall[w->W[k]] = w->y[k];
@@ -564,7 +573,12 @@ static int solve_dense(const form_t *f, const double *xk, const double *ref, dou
     if (smin >= 0) { for (int r = 0; r < nc; ++r) w->lam[r] = 0; return TMPC_STATUS_OPTIMAL; }
     {
         double viol = -smin, fl = 0.1 * (viol > 1.0 ? viol : 1.0);
-        for (int r = 0; r < nc; ++r) { if (w->s[r] < fl) w->s[r] = fl; w->lam[r] = 1.0; }
+        /* experiment knobs (developer only): ORACLE_INIT_FL scales the slack floor, ORACLE_INIT_LAM sets lambda_0,
+         * ORACLE_INIT_MU > 0 uses the centred start lambda_i = mu / s_i instead */
+        const char *e1 = getenv("ORACLE_INIT_FL"), *e2 = getenv("ORACLE_INIT_LAM"), *e3 = getenv("ORACLE_INIT_MU");
+        const double cfl = e1 ? atof(e1) : 1.0, l0 = e2 ? atof(e2) : 1.0, mu0 = e3 ? atof(e3) : 0.0;
+        fl *= cfl;
+        for (int r = 0; r < nc; ++r) { if (w->s[r] < fl) w->s[r] = fl; w->lam[r] = mu0 > 0 ? mu0 / w->s[r] : l0; }
     }
     double try_tol = tol;
     int status = TMPC_STATUS_MAX_ITER;

@@ -959,33 +959,35 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         dmax = wave_max(dmax);
                         if (lane < m) S[lane * (WCAP + 1) + lane] += 1e-11 * dmax;
                         wave_lds_fence();
-                        // Cholesky of S in LDS, right-looking; lane a owns row a
-                        bool spd = true;
-                        for (int j = 0; j < m; ++j) {
-                            const double pjj = S[j * (WCAP + 1) + j];
-                            if (!(pjj > 0.0)) { spd = false; break; }
-                            const double piv = sqrt(pjj);
-                            double lij = 0.0;
-                            if (lane > j && lane < m) lij = S[lane * (WCAP + 1) + j] / piv;
-                            wave_lds_fence();
-                            if (lane == j) S[j * (WCAP + 1) + j] = piv;
-                            if (lane > j && lane < m) S[lane * (WCAP + 1) + j] = lij;
-                            wave_lds_fence();
-                            // trailing update: row `lane`, columns j+1..lane
-                            if (lane > j && lane < m) {
-                                for (int c2 = j + 1; c2 <= lane; ++c2)
-                                    S[lane * (WCAP + 1) + c2] -= lij * S[c2 * (WCAP + 1) + j];
-                            }
-                            wave_lds_fence();
+                        // S by rows in registers (lane a holds row a; identity rows beyond m), LDL' by readlane elimination
+                        // like the normal matrix: no LDS round trips on the factorisation's and the solves' critical paths
+                        double srow[WCAP], sdinv = 1.0;
+#pragma unroll
+                        for (int c2 = 0; c2 < WCAP; ++c2) {
+                            const double v = S[(lane < WCAP ? lane : 0) * (WCAP + 1) + c2];
+                            srow[c2] = (lane < m && c2 < m) ? v : ((c2 == lane) ? 1.0 : 0.0);
                         }
-                        if (!spd) break;
-                        // four proximal Newton steps on the KKT system of the working set
+                        {
+                            double bdummy = 0.0;
+                            if (!rows_factor<WCAP>(srow, bdummy, sdinv, lane)) break;
+                        }
+                        // the refinement iterate lives in LDS (zpv), one entry per lane updates it
+                        double *zpv = dzav;
+                        if (lane < NV) {
+                            double mine = 0.0;
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) mine = (lane == j) ? zp[j] : mine;
+                            zpv[lane] = mine;
+                        }
+                        wave_lds_fence();
+                        // proximal Newton steps on the KKT system of the working set (at most four; they stop once a step
+                        // no longer moves the iterate)
                         for (int stp = 0; stp < 4; ++stp) {
                             // r1 = Hs zp + q + G_W' y   (lane i -> entry i)
                             if (lane < NV) {
                                 double v = qv[lane];
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v += Hs[lane * NV + j] * zp[j];
+                                for (int j = 0; j < NV; ++j) v += Hs[lane * NV + j] * zpv[j];
                                 for (int k = 0; k < m; ++k) v += GW[k * NV + lane] * yv[k];
                                 tv[lane] = v;
                             }
@@ -999,40 +1001,34 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             }
                             wave_lds_fence();
                             // dy rhs: (G_W zp - h_W) - G_W t1
+                            double bb = 0.0;
                             if (lane < m) {
                                 const int r = Widx[lane];
                                 double gz = 0.0, gt = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * NV + j]; gz += g * zp[j]; gt += g * uv[j]; }
+                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * NV + j]; gz += g * zpv[j]; gt += g * uv[j]; }
                                 const int sl = r < nd ? r : NDP + (r - nd);
-                                dyv[lane] = gz - hw[sl] - gt;
+                                bb = gz - hw[sl] - gt;
+                            }
+                            rows_forward<WCAP>(srow, bb, lane);
+                            const double dyl = rows_backsub_lane<WCAP>(srow, bb, sdinv, lane);
+                            if (lane < m) { dyv[lane] = dyl; yv[lane] += dyl; }
+                            wave_lds_fence();
+                            // zp -= t1 + T dy  (lane j -> entry j)
+                            double dzl = 0.0, zl = 0.0;
+                            if (lane < NV) {
+                                double v = uv[lane];
+                                for (int k = 0; k < m; ++k) v += T[lane * WCAP + k] * dyv[k];
+                                zl = zpv[lane] - v;
+                                zpv[lane] = zl;
+                                dzl = fabs(v);
                             }
                             wave_lds_fence();
-                            // forward / backward substitution with L (in S), m sequential steps each
-                            for (int j = 0; j < m; ++j) {
-                                const double vj = dyv[j] / S[j * (WCAP + 1) + j];
-                                wave_lds_fence();
-                                if (lane == j) dyv[j] = vj;
-                                if (lane > j && lane < m) dyv[lane] -= S[lane * (WCAP + 1) + j] * vj;
-                                wave_lds_fence();
-                            }
-                            for (int j = m - 1; j >= 0; --j) {
-                                const double vj = dyv[j] / S[j * (WCAP + 1) + j];
-                                wave_lds_fence();
-                                if (lane == j) dyv[j] = vj;
-                                if (lane < j) dyv[lane] -= S[j * (WCAP + 1) + lane] * vj;
-                                wave_lds_fence();
-                            }
-                            // zp -= t1 + T dy ; y += dy
-#pragma unroll
-                            for (int j = 0; j < NV; ++j) {
-                                double v = uv[j];
-                                for (int k = 0; k < m; ++k) v += T[j * WCAP + k] * dyv[k];
-                                zp[j] -= v;
-                            }
-                            if (lane < m) yv[lane] += dyv[lane];
-                            wave_lds_fence();
+                            const double dzn = wave_max(dzl), zn = wave_max(fabs(zl));
+                            if (stp >= 1 && dzn <= 1e-14 * fmax(zn, 1.0)) break;
                         }
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) zp[j] = zpv[j];
                     }
                     // ---- verify: primal feasibility on all rows, sign of y on W
                     double ymax = 1.0;
