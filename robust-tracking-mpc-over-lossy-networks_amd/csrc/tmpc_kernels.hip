@@ -151,10 +151,11 @@ __device__ __forceinline__ void wave_reduce_to_lds(const double (&acc)[CNT], dou
 template <int NV>
 __host__ __device__ constexpr int col_off(int j) { return j * NV - j * (j - 1) / 2; }
 
-// Column blocks of the lower triangle accumulated per sweep (<= ~40 accumulators each).
+// Column blocks of the lower triangle accumulated per sweep.  NV <= 12: one block (<= 90 accumulators fit the 512
+// registers of a lone wave and save re-reading the rows; measured 3 % on the bench shape); larger NV: <= ~40 each.
 template <int NV> struct Blocks;
-template <> struct Blocks<8>  { static constexpr int n = 2; static constexpr int b[3] = {0, 3, 8}; };
-template <> struct Blocks<12> { static constexpr int n = 3; static constexpr int b[4] = {0, 3, 7, 12}; };
+template <> struct Blocks<8>  { static constexpr int n = 1; static constexpr int b[3] = {0, 8, 8}; };
+template <> struct Blocks<12> { static constexpr int n = 1; static constexpr int b[4] = {0, 12, 12, 12}; };
 template <> struct Blocks<16> { static constexpr int n = 5; static constexpr int b[6] = {0, 2, 4, 7, 11, 16}; };
 template <> struct Blocks<24> { static constexpr int n = 10; static constexpr int b[11] = {0, 1, 3, 5, 7, 9, 11, 14, 17, 20, 24}; };
 
