@@ -78,13 +78,20 @@ def main():
     import common
     from LinearMPCOverNetworks import _native
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # TMPC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share the devices, the
+    # statistics gather goes through host memory); the driver's runs use nccl (= RCCL), one rank per GPU
+    backend = os.environ.get("TMPC_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
-    mpc, w = common.make_mpc("cartpole", 10, True, create=True, device=local_rank)
+    mpc, w = common.make_mpc("cartpole", 10, True, create=True, device=dev_index)
     h = mpc._handle
     nv, nc, npar = _native.get_dims(h, 0)
     nx, nu, N = 4, 1, 10
@@ -119,6 +126,8 @@ def main():
         # the only exchange of the path: per-trajectory statistics, gathered once per sweep
         # (RCCL all-gather over xGMI; 8 B per trajectory, latency-bound)
         stats = torch.stack([st, it], dim=1).contiguous()
+        if backend != "nccl":
+            stats = stats.cpu()
         return montecarlo.gather_statistics(stats, world * B, rank, world)
 
     for _ in range(args.warmup):
@@ -135,7 +144,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
