@@ -196,6 +196,17 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
                 const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
                 int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent);
 
+/*
+ * Plant simulated by tmpc_mc_run.  TMPC_PLANT_LINEAR (default): x+ = A x + B u + w (results_linear_system.py:248).
+ * TMPC_PLANT_CARTPOLE: the nonlinear cart-pole the linear model was derived from (results_linear_system.py:26-47;
+ * the reference integrates it with PyBullet at 500 Hz, results_nonlinear_system.py:30-37), zero-order hold of the
+ * input over the sampling period, classical RK4 with `substeps` steps; w is added to the result (pass zeros).
+ * par = {M, m, b, I, g, l, Th}.  Needs nx = 4, nu = 1.
+ */
+#define TMPC_PLANT_LINEAR   0
+#define TMPC_PLANT_CARTPOLE 1
+int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps);
+
 /* Block until everything enqueued on the handle's stream has finished. */
 int tmpc_synchronize(tmpc_handle *h);
 

@@ -89,6 +89,8 @@ def lib():
         L.tmpc_get_kernel_path.restype = C.c_int
         L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 5
         L.tmpc_mc_run.restype = C.c_int
+        L.tmpc_mc_set_plant.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
+        L.tmpc_mc_set_plant.restype = C.c_int
         L.tmpc_synchronize.argtypes = [C.c_void_p]
         L.tmpc_synchronize.restype = C.c_int
         L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -257,6 +259,20 @@ def get_kernel_path(h: Handle, variant: int = 0) -> str:
     if code < 0:
         raise RuntimeError("tmpc_get_kernel_path failed")
     return {v: k for k, v in KERNEL_PATHS.items()}[code]
+
+
+def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
+    """include/tmpc.h: tmpc_mc_set_plant.  plant: None / 'linear', or 'cartpole' (workloads.CARTPOLE_PARAMS)."""
+    if plant in (None, "linear"):
+        rc = lib().tmpc_mc_set_plant(h.ptr, 0, None, 0)
+    elif plant == "cartpole":
+        from .workloads import CARTPOLE_PARAMS as P
+        par = (C.c_double * 7)(P["M"], P["m"], P["b"], P["I"], P["g"], P["l"], float(Th))
+        rc = lib().tmpc_mc_set_plant(h.ptr, 1, par, int(substeps))
+    else:
+        raise ValueError(f"unknown plant {plant!r}")
+    if rc != 0:
+        raise RuntimeError(h.error())
 
 
 def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False) -> dict:

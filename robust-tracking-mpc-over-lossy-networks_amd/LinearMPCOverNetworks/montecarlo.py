@@ -67,7 +67,8 @@ def draw_realisations(n_traj: int, T: int, w_bound, seed: int = 20240301, first:
     return th, ga, w
 
 
-def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False):
+def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False,
+                        plant=None):
     """Closed loop of the remote tube-based MPC over a lossy network for a batch of trajectories:
     the body of the reference's Monte-Carlo loop (results_linear_system.py:209-259, 291) with the
     per-trajectory objects replaced by the batched state machines and the QP solves of one time
@@ -79,6 +80,8 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     estimator is the RobustEstimator (it also stores x_nom_0, :279) and the actuator adopts x_nom_0 (:133-147).
 
     p_loss (B,), ref (T,) position reference, th_u/ga_u (B,T) uniforms, w (B,T,nx) disturbances.
+    plant: None = the linear model x+ = A x + B u + w (:248); or a callable (x (B,nx), u (B,nu)) -> x+ (w is added to it),
+    e.g. workloads.cartpole_step for the nonlinear cart-pole of results_nonlinear_system.py.
     Returns a dict of per-trajectory statistics."""
     from .Estimator import BatchedEstimator
     from .SmartActuator import BatchedConsistentActuator
@@ -123,7 +126,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
         # after adopting the packet's x_nom_0, SmartActuator.py:219-222)
         x_nom_now = pkt["x_nom_t"] if extended else pkt["x_t"]
         tube_viol += ~np.asarray(Z.contains((x - x_nom_now).T)).reshape(nb)
-        x = x @ A.T + u @ Bm.T + w[:, t]                                                           # :248
+        x = (x @ A.T + u @ Bm.T if plant is None else plant(x, u)) + w[:, t]                      # :248
         gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :218-226
         est.update(pkt, gamma)                                                                     # :254
         # Proposition 1 of the paper: whenever the actuator is consistent and the plant packet arrives,
@@ -135,8 +138,18 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
                 consistent_estimate_error=consistent_err, x_final=x)
 
 
+def plant_callable(plant):
+    """'cartpole' -> the numpy counterpart of the device plant (workloads.cartpole_step); callables pass through."""
+    if callable(plant):
+        return plant
+    if plant == "cartpole":
+        from . import workloads
+        return lambda x, u: workloads.cartpole_step(x, u[:, 0])
+    raise ValueError(f"unknown plant {plant!r}")
+
+
 def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
-             extended: bool = False, device=None, on_device: bool = False):
+             extended: bool = False, device=None, on_device: bool = False, plant=None):
     """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
     trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
     shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
@@ -150,11 +163,11 @@ def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240
     th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
     ref = np.broadcast_to(np.asarray(ref, dtype=np.float64), (T,))
     if on_device:        # state machines on the GPU as well (tmpc_mc_run); otherwise the host loop around determine_packets
-        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended)
+        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended, plant=plant)
     else:
         out = run_remote_tube_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
                                   mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, p_loss[pi[lo:hi]], ref, th, ga, w,
-                                  extended=extended)
+                                  extended=extended, plant=None if plant is None else plant_callable(plant))
     local = torch.tensor(np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]], dtype=torch.float64)
     if device is not None:
         local = local.to(device)

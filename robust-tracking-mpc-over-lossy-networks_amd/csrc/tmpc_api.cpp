@@ -51,6 +51,8 @@ struct tmpc_handle {
     double *ws_s = nullptr, *ws_lam = nullptr, *ws_z = nullptr;
     int32_t *ws_stat = nullptr, *ws_it = nullptr;
     std::vector<double> hA, hB, hK, hKanc;   // host copies for the closed-loop entry point
+    int plant = TMPC_PLANT_LINEAR, plant_substeps = 10;
+    double plant_par[7] = {0, 0, 0, 0, 0, 0, 0};
     int kernel_path = TMPC_PATH_AUTO;
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
     int blk_ncp = 0;
@@ -485,6 +487,17 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
     return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;
 }
 
+int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps) {
+    if (!h) return TMPC_E_INVALID;
+    if (kind == TMPC_PLANT_LINEAR) { h->plant = kind; return TMPC_OK; }
+    if (kind != TMPC_PLANT_CARTPOLE || !par7 || substeps < 1) { h->err = "tmpc_mc_set_plant: unknown plant or missing parameters"; return TMPC_E_INVALID; }
+    if (h->nx != 4 || h->nu != 1) { h->err = "tmpc_mc_set_plant: the cart-pole plant needs nx = 4, nu = 1"; return TMPC_E_INVALID; }
+    for (int i = 0; i < 7; ++i) h->plant_par[i] = par7[i];
+    h->plant = kind;
+    h->plant_substeps = substeps;
+    return TMPC_OK;
+}
+
 int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
                 const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
                 int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent) {
@@ -517,6 +530,8 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
         tmpc::McModel m{};
         tmpc::McState st{};
         m.nx = h->nx; m.nu = h->nu; m.N = h->N; m.extended = extended ? 1 : 0; m.rZ = rZ;
+        m.plant = h->plant; m.substeps = h->plant_substeps;
+        for (int i = 0; i < 7; ++i) m.par[i] = h->plant_par[i];
         int r2;
         if ((r2 = up(h->hA.data(), nx * nx * 8, reinterpret_cast<const void **>(&m.A)))) return r2;
         if ((r2 = up(h->hB.data(), nx * nu * 8, reinterpret_cast<const void **>(&m.B)))) return r2;

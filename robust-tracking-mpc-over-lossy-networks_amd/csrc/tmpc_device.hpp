@@ -88,6 +88,8 @@ hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double
 // Device-resident closed loop (tmpc_mc.hip)
 struct McModel {
     int nx, nu, N, extended, rZ;
+    int plant, substeps;                 // TMPC_PLANT_*, RK4 steps per sampling period
+    double par[7];                       // cart-pole: M, m, b, I, g, l, Th
     const double *A, *B, *K, *K_anc;     // model and gains (row-major)
     const double *HZ, *hZ;               // tube cross-section Z for the membership check
 };

@@ -26,6 +26,21 @@ namespace {
 
 constexpr int MAXN = 16;      // nx, nu <= 16 (tmpc_create enforces nx <= 16; nu checked by the launcher)
 
+// cart-pole about the upright position, x = [pos, vel, angle, angular velocity] (LinearMPCOverNetworks/workloads.py:
+// cartpole_rhs has the derivation and the numpy twin)
+__device__ __forceinline__ void cartpole_rhs(const double *par, const double (&x)[4], double F, double (&dx)[4]) {
+    const double M = par[0], m = par[1], b = par[2], I = par[3], g = par[4], l = par[5];
+    const double s = sin(x[2]), c = cos(x[2]);
+    const double a11 = M + m, a12 = m * l * c, a22 = I + m * l * l;
+    const double r1 = F - b * x[1] + m * l * x[3] * x[3] * s;
+    const double r2 = m * g * l * s;
+    const double det = a11 * a22 - a12 * a12;
+    dx[0] = x[1];
+    dx[1] = (r1 * a22 - a12 * r2) / det;
+    dx[2] = x[3];
+    dx[3] = (a11 * r2 - a12 * r1) / det;
+}
+
 __global__ void mc_pre_kernel(const McModel m, const McState st, const int t, const int64_t B, const double ref_t) {
     const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -102,6 +117,23 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
         for (int j = 0; j < nu; ++j) { v += m.B[i * nu + j] * u[j]; vn += m.B[i * nu + j] * un[j]; }
         xp[i] = v;
         xnp[i] = vn;
+    }
+    if (m.plant == TMPC_PLANT_CARTPOLE) {
+        // zero-order hold of u over the sampling period, RK4 at the physics rate; the nominal model stays linear
+        double y[4] = {x[0], x[1], x[2], x[3]};
+        const double dt = m.par[6] / m.substeps;
+        for (int sstep = 0; sstep < m.substeps; ++sstep) {
+            double k1[4], k2[4], k3[4], k4[4], yt[4];
+            cartpole_rhs(m.par, y, u[0], k1);
+            for (int i = 0; i < 4; ++i) yt[i] = y[i] + 0.5 * dt * k1[i];
+            cartpole_rhs(m.par, yt, u[0], k2);
+            for (int i = 0; i < 4; ++i) yt[i] = y[i] + 0.5 * dt * k2[i];
+            cartpole_rhs(m.par, yt, u[0], k3);
+            for (int i = 0; i < 4; ++i) yt[i] = y[i] + dt * k3[i];
+            cartpole_rhs(m.par, yt, u[0], k4);
+            for (int i = 0; i < 4; ++i) y[i] += dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+        }
+        for (int i = 0; i < 4; ++i) xp[i] = y[i] + st.w[(b * T + t) * nx + i];
     }
     for (int i = 0; i < nx; ++i) { st.x[b * nx + i] = xp[i]; st.x_nom[b * nx + i] = xnp[i]; }
     // ---- estimator (Estimator.py:43-98; robust: :113-156)

@@ -105,3 +105,39 @@ def test_device_resident_loop_equals_host_loop(hip_lib, extended):
     np.testing.assert_allclose(dev["tracking_error"], host["tracking_error"], atol=1e-10, rtol=0)
     if not extended:
         assert dev["consistent_estimate_error"] < 1e-9
+
+
+def test_nonlinear_cartpole_linearises_to_the_reference_model():
+    """The cart-pole ODE used as the nonlinear plant, held over one sampling period (RK4, 500 Hz), has exactly the
+    (A, B) of results_linear_system.py:35-61 as its Jacobian at the upright equilibrium."""
+    from LinearMPCOverNetworks import workloads
+    w = workloads.cartpole()
+    eps = 1e-6
+    A_fd = np.array([(workloads.cartpole_step(np.eye(4)[i] * eps, np.zeros(())) - workloads.cartpole_step(-np.eye(4)[i] * eps, np.zeros(())))
+                     / (2 * eps) for i in range(4)]).T
+    B_fd = (workloads.cartpole_step(np.zeros(4), np.array(eps)) - workloads.cartpole_step(np.zeros(4), np.array(-eps))) / (2 * eps)
+    np.testing.assert_allclose(A_fd, w["A"], atol=1e-9)
+    np.testing.assert_allclose(B_fd, w["B"][:, 0], atol=1e-9)
+    # energy-like sanity: without force and friction the upright equilibrium is a fixed point
+    np.testing.assert_allclose(workloads.cartpole_step(np.zeros(4), np.zeros(())), 0.0, atol=0)
+
+
+@pytest.mark.gpu
+def test_device_loop_with_nonlinear_plant_equals_host_loop(hip_lib):
+    """Remote tube MPC (linear model inside) driving the NONLINEAR cart-pole, device loop vs numpy loop."""
+    nb, T = 64, 100
+    mpc, w, p_loss, th, ga, dist, ref = _setup(nb, T, seed=31)
+    mpc_gpu, _ = common.make_mpc("cartpole", 10, True, create=True)
+    dist = 0.0 * dist                                      # the mismatch between model and plant is the disturbance
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    host = montecarlo.run_remote_tube_mpc(mpc_gpu.determine_packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist,
+                                          plant=montecarlo.plant_callable("cartpole"))
+    dev = mpc_gpu.run_closed_loop(p_loss, ref, th, ga, dist, plant="cartpole")
+    lin = mpc_gpu.run_closed_loop(p_loss, ref, th, ga, dist)             # back to the linear plant: the setting is per call
+    assert np.all(dev["not_optimal"] == 0)
+    np.testing.assert_allclose(dev["x_final"], host["x_final"], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(dev["tracking_error"], host["tracking_error"], atol=1e-10, rtol=0)
+    assert np.array_equal(dev["tube_violations"], host["tube_violations"])
+    # the nonlinear plant really is a different plant, and the loop still tracks the reference
+    assert np.max(np.abs(dev["x_final"] - lin["x_final"])) > 1e-6
+    assert np.all(dev["x_final"][:, 0] > 0.2) and np.max(np.abs(dev["x_final"][:, 2])) < 0.05     # 2 s in: on its way, pole upright
