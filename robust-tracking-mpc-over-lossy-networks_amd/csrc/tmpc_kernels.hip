@@ -33,6 +33,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 #include <utility>
 
 #include "tmpc_device.hpp"
@@ -44,7 +45,7 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WCAP = 24;          // max rows in the refinement's working set
-constexpr int RED_ROWS = 16;      // entries per transposition round
+constexpr int RED_ROWS_MAX = 16;  // entries per transposition round (12 in the two-waves-per-SIMD build: smaller tile)
 constexpr int RED_STRIDE = 68;    // 64 lanes + a pad after every 16: conflict-free transposed reads
 
 // Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of the first wave, written to
@@ -127,22 +128,23 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
 // l + l/16, i.e. one pad after every 16 lanes); lane l then adds the 16-lane quarter (l & 3) of
 // entry (l >> 2) -- conflict free for RED_STRIDE = 68 -- and the four quarters, which sit in one
 // quad, meet through two DPP quad permutes (no LDS round trip).
-template <int CNT>
+template <int CNT, int RR = RED_ROWS_MAX>
 __device__ __forceinline__ void wave_reduce_to_lds(const double (&acc)[CNT], double *red, double *out, int lane) {
     const int e = lane >> 2, qd = lane & 3;
+    const int er = (RR < 16 && e >= RR) ? 0 : e;          // RR < 16: the lanes of entries RR..15 idle along
     const int wcol = lane + (lane >> 4);
 #pragma unroll
-    for (int c0 = 0; c0 < CNT; c0 += RED_ROWS) {
+    for (int c0 = 0; c0 < CNT; c0 += RR) {
 #pragma unroll
-        for (int k = 0; k < RED_ROWS; ++k)
+        for (int k = 0; k < RR; ++k)
             if (c0 + k < CNT) red[k * RED_STRIDE + wcol] = acc[c0 + k];
         wave_lds_fence();
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[e * RED_STRIDE + qd * 17 + j];
+        for (int j = 0; j < 16; ++j) t += red[er * RED_STRIDE + qd * 17 + j];
         t += dpp_mov_d<0xB1>(t);
         t += dpp_mov_d<0x4E>(t);
-        if (qd == 0 && c0 + e < CNT) out[c0 + e] = t;
+        if (qd == 0 && e < RR && c0 + e < CNT) out[c0 + e] = t;
         wave_lds_fence();
     }
 }
@@ -158,6 +160,10 @@ template <> struct Blocks<8>  { static constexpr int n = 1; static constexpr int
 template <> struct Blocks<12> { static constexpr int n = 1; static constexpr int b[4] = {0, 12, 12, 12}; };
 template <> struct Blocks<16> { static constexpr int n = 5; static constexpr int b[6] = {0, 2, 4, 7, 11, 16}; };
 template <> struct Blocks<24> { static constexpr int n = 10; static constexpr int b[11] = {0, 1, 3, 5, 7, 9, 11, 14, 17, 20, 24}; };
+// the register-lean build keeps <= ~40 accumulators per pass
+template <int NV> struct BlocksLean : Blocks<NV> {};
+template <> struct BlocksLean<8>  { static constexpr int n = 2; static constexpr int b[3] = {0, 3, 8}; };
+template <> struct BlocksLean<12> { static constexpr int n = 3; static constexpr int b[4] = {0, 3, 7, 12}; };
 
 // ---- nv x nv solve, rows distributed over lanes.
 // Lane i (< NV) holds row i of the symmetric positive definite M in registers.  Gaussian
@@ -218,9 +224,13 @@ __device__ __forceinline__ double rows_backsub_lane(const double (&row)[NV], dou
 }
 
 // compile-time description of one kernel instantiation
-template <int NV_, int RD_, int KC_, int RC_>
+// DIET: the build for two waves per SIMD (eight waves per workgroup): at most 256 registers and ~14 KB of LDS per wave,
+// paid for with a smaller transposition tile and the column-blocked accumulation
+template <int NV_, int RD_, int KC_, int RC_, bool DIET_ = false>
 struct Shape {
     static constexpr int NV = NV_, RD = RD_, KC = KC_, RC = RC_;
+    static constexpr bool DIET = DIET_;
+    static constexpr int RR = DIET_ ? 12 : RED_ROWS_MAX;
     static constexpr int KCA = KC_ > 0 ? KC_ : 1;            // array extents must be positive
     static constexpr int RT = RD_ + RC_;                     // 64-row slots per lane
     static constexpr int NDP = RD_ * WAVE, NCCP = RC_ * WAVE;
@@ -230,8 +240,8 @@ struct Shape {
 // per-wave LDS workspace (doubles), see solve_kernel
 template <class SH>
 struct WaveLds {
-    static constexpr int RED = RED_ROWS * RED_STRIDE;                                   // transposition tile
-    static constexpr int POL = 2 * SH::NV * WCAP + WCAP * (WCAP + 1) + 4 * WCAP;       // G_W, T, S, y, dy, W(idx)
+    static constexpr int RED = SH::RR * RED_STRIDE;                                     // transposition tile
+    static constexpr int POL = 2 * SH::NV * WCAP + 4 * WCAP;                             // G_W, T, y, dy, W(idx)
     static constexpr int BIG = RED > POL ? RED : POL;                                   // never live together
     static constexpr int SUMS = SH::NT + 2 * SH::NV + 8;                                // dense totals of a sweep
     static constexpr int CSUMS = SH::KT + 2 * SH::KC + 8;                               // factored-block totals
@@ -343,10 +353,10 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
         for (int i = 0; i < TRI; ++i) tri[i] = acc[i];
 #pragma unroll
         for (int i = 0; i < NV; ++i) vecs[i] = acc[TRI + i];
-        if constexpr (TRI > 0) wave_reduce_to_lds<TRI>(tri, red, sums + col_off<NV>(J0), lane);
-        wave_reduce_to_lds<NV>(vecs, red, sums + NT, lane);
+        if constexpr (TRI > 0) wave_reduce_to_lds<TRI, SH::RR>(tri, red, sums + col_off<NV>(J0), lane);
+        wave_reduce_to_lds<NV, SH::RR>(vecs, red, sums + NT, lane);
     } else {
-        wave_reduce_to_lds<CNT>(acc, red, sums + col_off<NV>(J0), lane);
+        wave_reduce_to_lds<CNT, SH::RR>(acc, red, sums + col_off<NV>(J0), lane);
     }
 }
 
@@ -355,7 +365,7 @@ __device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double
                                                   const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                                   double (&dd)[SH::RD > 0 ? SH::RD : 1],
                                                   double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
-    using BL = Blocks<SH::NV>;
+    using BL = std::conditional_t<SH::DIET, BlocksLean<SH::NV>, Blocks<SH::NV>>;
     if constexpr (BI < BL::n) {
         sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
         sweep_a_dense_all<SH, BI + 1>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
@@ -393,7 +403,7 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
             acc[KT + a] += hc[a] * t;
         }
     }
-    wave_reduce_to_lds<KT + KC>(acc, red, csums, lane);
+    wave_reduce_to_lds<KT + KC, SH::RR>(acc, red, csums, lane);
 }
 
 // (G_row . z, G_row . d1[, G_row . d2]) for the row in (slot K, this lane), sharing the row's loads
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
-    using SH = Shape<NV, RD, KC, RC>;
+    using SH = Shape<NV, RD, KC, RC, WPB == 8>;
     using WL = WaveLds<SH>;
     constexpr int RT = SH::RT, NDP = SH::NDP, NCCP = SH::NCCP, NT = SH::NT, KT = SH::KT, KCA = SH::KCA;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             for (int j = 0; j < NV; ++j) accl[j] += Gt[j * NDP + r] * lam[k];
                             row_fence();
                         }
-                        wave_reduce_to_lds<NV>(accl, red, sums + NT + NV, lane);
+                        wave_reduce_to_lds<NV, SH::RR>(accl, red, sums + NT + NV, lane);
                     }
                     if constexpr (KC > 0) {
                         double accl[KC];
@@ -680,7 +690,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #pragma unroll
                             for (int a = 0; a < KC; ++a) accl[a] += Hct[a * NCCP + rc] * lam[k];
                         }
-                        wave_reduce_to_lds<KC>(accl, red, csums + KT + KC, lane);
+                        wave_reduce_to_lds<KC, SH::RR>(accl, red, csums + KT + KC, lane);
                         double gl = 0.0;
                         if (lane < NV) {
                             gl = (RD > 0) ? sums[NT + NV + lane] : 0.0;
@@ -787,7 +797,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             for (int j = 0; j < NV; ++j) { accb[j] += g[j] * c1; accb[NV + j] += g[j] * rsk; }
                             row_fence();
                         }
-                        wave_reduce_to_lds<2 * NV>(accb, red, sums + NT, lane);   // overwrites G'(d.rp), G'lam (consumed)
+                        wave_reduce_to_lds<2 * NV, SH::RR>(accb, red, sums + NT, lane);   // overwrites G'(d.rp), G'lam (consumed)
                     }
                     if constexpr (KC > 0) {
                         double accc[2 * KC];
@@ -806,7 +816,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             for (int a = 0; a < KC; ++a) { accc[a] += hc[a] * c1; accc[KC + a] += hc[a] * rsk; }
                             row_fence();
                         }
-                        wave_reduce_to_lds<2 * KC>(accc, red, csums + KT, lane);
+                        wave_reduce_to_lds<2 * KC, SH::RR>(accc, red, csums + KT, lane);
                     }
                     rho_aff = wave_max(rho_aff);
                     sb1 = wave_sum(sb1);
@@ -886,8 +896,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 // workspace carved from the (now idle) transposition tile
                 double *GW = red;                         // [WCAP][NV]  rows of the working set, expanded
                 double *T = GW + WCAP * NV;               // [NV][WCAP]
-                double *S = T + NV * WCAP;                // [WCAP][WCAP+1]
-                double *yv = S + WCAP * (WCAP + 1);       // [WCAP]
+                double *yv = T + NV * WCAP;               // [WCAP]
                 double *dyv = yv + WCAP;                  // [WCAP]
                 int *Widx = reinterpret_cast<int *>(dyv + WCAP);   // [WCAP] global row ids
                 bool inW[RT];
@@ -946,27 +955,27 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             T[i * WCAP + k] = v;
                         }
                         wave_lds_fence();
-                        // S = G_W T (+ delta I)
-                        for (int idx = lane; idx < m * m; idx += WAVE) {
-                            const int a = idx / m, c2 = idx - a * m;
-                            double v = 0.0;
-#pragma unroll
-                            for (int j = 0; j < NV; ++j) v += GW[a * NV + j] * T[j * WCAP + c2];
-                            S[a * (WCAP + 1) + c2] = v;
-                        }
-                        wave_lds_fence();
-                        double dmax = 0.0;
-                        if (lane < m) dmax = S[lane * (WCAP + 1) + lane];
-                        dmax = wave_max(dmax);
-                        if (lane < m) S[lane * (WCAP + 1) + lane] += 1e-11 * dmax;
-                        wave_lds_fence();
-                        // S by rows in registers (lane a holds row a; identity rows beyond m), LDL' by readlane elimination
-                        // like the normal matrix: no LDS round trips on the factorisation's and the solves' critical paths
+                        // S = G_W T (+ delta I) by rows in registers: lane a holds row a (identity rows beyond m); LDL' by
+                        // readlane elimination like the normal matrix -- no LDS round trips on the critical paths
                         double srow[WCAP], sdinv = 1.0;
+                        {
+                            double gw[NV];
+                            const int la = lane < m ? lane : 0;
 #pragma unroll
-                        for (int c2 = 0; c2 < WCAP; ++c2) {
-                            const double v = S[(lane < WCAP ? lane : 0) * (WCAP + 1) + c2];
-                            srow[c2] = (lane < m && c2 < m) ? v : ((c2 == lane) ? 1.0 : 0.0);
+                            for (int j = 0; j < NV; ++j) gw[j] = GW[la * NV + j];
+                            double sdiag = 0.0;
+#pragma unroll
+                            for (int c2 = 0; c2 < WCAP; ++c2) {
+                                double v = 0.0;
+#pragma unroll
+                                for (int j = 0; j < NV; ++j) v += gw[j] * T[j * WCAP + c2];
+                                const bool in = lane < m && c2 < m;
+                                srow[c2] = in ? v : ((c2 == lane) ? 1.0 : 0.0);
+                                if (c2 == lane && in) sdiag = v;
+                            }
+                            const double dmax = wave_max(sdiag);
+#pragma unroll
+                            for (int c2 = 0; c2 < WCAP; ++c2) if (c2 == lane && lane < m) srow[c2] += 1e-11 * dmax;
                         }
                         {
                             double bdummy = 0.0;
@@ -1152,17 +1161,27 @@ constexpr size_t kernel_lds_bytes(int wpb) {
                              static_cast<size_t>(wpb) * WaveLds<SH>::TOTAL);
 }
 // four waves per workgroup (one per SIMD) unless the per-wave workspace does not leave room for that
-template <class SH>
+template <int NV, int RD, int KC, int RC>
 constexpr int waves_per_block() {
-    return kernel_lds_bytes<SH>(4) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3) <= 160 * 1024 ? 3 : 2);
+    using SH = Shape<NV, RD, KC, RC, false>;
+    // NV = 24 stays at three waves: with four, solve_kernel<24,3,6,7> faulted (memory aperture violation) on the MI355X --
+    // not understood yet, the three-wave build is the one the parity tests have always run
+    return NV >= 24 ? (kernel_lds_bytes<SH>(3) <= 160 * 1024 ? 3 : 2)
+                    : (kernel_lds_bytes<SH>(4) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3) <= 160 * 1024 ? 3 : 2));
+}
+// eight waves per workgroup (two per SIMD, register-lean build) where that fits the LDS; worth it once every SIMD
+// has more than one instance to work on (measured on the bench shape: 1.08 vs 1.20 ms at B = 4096, but 0.44 vs
+// 0.29 ms for a single instance -- the 256-register cap costs spills)
+template <int NV, int RD, int KC, int RC>
+constexpr bool fits_two_per_simd() {
+    return NV <= 12 && kernel_lds_bytes<Shape<NV, RD, KC, RC, true>>(8) <= 160 * 1024;
 }
 
-template <int NV, int RD, int KC, int RC, bool WARM>
-hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id, int64_t B, const double *x_k, const double *ref,
+template <int NV, int RD, int KC, int RC, bool WARM, int WPB>
+hipError_t launch_wpb(const DeviceQP &qp, const WarmStart &warm, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
-    using SH = Shape<NV, RD, KC, RC>;
-    constexpr int WPB = waves_per_block<SH>();
+    using SH = Shape<NV, RD, KC, RC, WPB == 8>;
     constexpr size_t lds = kernel_lds_bytes<SH>(WPB);
     static_assert(lds <= 160 * 1024, "shape does not fit the 160 KiB LDS of a CU");
     // > 64 KiB of dynamic LDS needs the opt-in once per device and instantiation
@@ -1176,12 +1195,25 @@ hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id,
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     int64_t blocks = (B + WPB - 1) / WPB;
-    const int64_t cap = static_cast<int64_t>(n_cu) * 4;     // a few workgroups per CU, grid-stride over the batch
+    const int64_t cap = static_cast<int64_t>(n_cu) * (WPB == 8 ? 2 : 4);     // a few workgroups per CU, grid-stride over the batch
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((solve_kernel<NV, RD, KC, RC, WARM, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
                        qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
     return hipGetLastError();
+}
+
+template <int NV, int RD, int KC, int RC, bool WARM>
+hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id, int64_t B, const double *x_k, const double *ref,
+                      const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
+                      int32_t *status, int32_t *iters, int n_cu, hipStream_t stream) {
+    if constexpr (fits_two_per_simd<NV, RD, KC, RC>()) {
+        if (B > static_cast<int64_t>(n_cu) * 4)
+            return launch_wpb<NV, RD, KC, RC, WARM, 8>(qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
+                                                        iters, n_cu, stream);
+    }
+    return launch_wpb<NV, RD, KC, RC, WARM, waves_per_block<NV, RD, KC, RC>()>(qp, warm, variant_id, B, x_k, ref, variant, u_nom, x_nom0,
+                                                                               xu_ss, x_nom, status, iters, n_cu, stream);
 }
 
 }  // namespace
@@ -1193,7 +1225,7 @@ hipError_t launch_one(const DeviceQP &qp, const WarmStart &warm, int variant_id,
     X(12, 2, 6, 7) X(24, 3, 6, 7)
 
 size_t lds_bytes(const KernelShape &s) {
-#define TMPC_LDS(A, B_, C, D) if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D) return kernel_lds_bytes<Shape<A, B_, C, D>>(waves_per_block<Shape<A, B_, C, D>>());
+#define TMPC_LDS(A, B_, C, D) if (s.nvp == A && s.rd == B_ && s.kcp == C && s.rc == D) return kernel_lds_bytes<Shape<A, B_, C, D, false>>(waves_per_block<A, B_, C, D>());
     TMPC_SHAPES(TMPC_LDS)
 #undef TMPC_LDS
     return 0;
