@@ -178,7 +178,7 @@ def main():
                        "mean_ipm_iters": float(iters_all.mean()), "optimal_fraction": float((status_all == 0).mean())},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "tmpc::solve_kernel<12,2,6,7,false,4>", "avg_kernel_ms": avg_kernel_s * 1e3,
+                         "kernel": "tmpc::solve_kernel<12,2,6,7,false,%d>" % (8 if B > 1024 else 4), "avg_kernel_ms": avg_kernel_s * 1e3,
                          "flops_per_launch": flops_launch,
                          "note": "bound is FP64 arithmetic (vector ALU; 78.6 TFLOP/s is also the FP64 MFMA peak), "
                                  "not HBM: algorithmic HBM bytes are %d B/solve" % bytes_solve,
