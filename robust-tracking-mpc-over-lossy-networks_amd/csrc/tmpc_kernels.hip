@@ -10,21 +10,20 @@
 //   2. z = -Hs^-1 q; if G z <= h the unconstrained minimiser is the answer
 //   3. Mehrotra predictor-corrector interior-point iterations on
 //         min 1/2 z'Hs z + q'z  s.t.  Gs z + s = h, s >= 0
-//      rows of Gs are spread over the lanes (row r lives on lane r % 64, slot r / 64), the
-//      per-row state (s, lambda, r_p, 1/s, ...) stays in registers, Gs is staged once per
-//      workgroup in LDS (column-major, so a lane-per-row read is conflict free); the rows of
-//      the terminal block are kept factored, Gs_T = Hc * Psi with Hc only nx+nth wide
-//      (tmpc_condense.hpp), which cuts their share of every sweep by nv/kc and of G'DG by
-//      (nv/kc)^2.  The
-//      normal matrix M = Hs + Gs' D Gs is accumulated per lane in registers, a few
-//      columns of its lower triangle at a time (the full triangle does not fit the 256
-//      directly addressable VGPRs next to the row state), and summed across the wave
-//      through an LDS transposition.  Its Cholesky factor and the solves are done
-//      redundantly by every lane in registers (nv <= 16); the factor is parked in LDS
-//      between the predictor and the corrector solve.
+//      rows of Gs are spread over the lanes (row r lives on lane r % 64, slot r / 64); (s, lambda) and the two
+//      carried row quantities (r_p, ds_aff * dl_aff) stay in registers, h in LDS; Gs is staged once per workgroup
+//      in LDS (column-major, so a lane-per-row read is conflict free); the rows of the terminal block are kept
+//      factored, Gs_T = Hc * Psi with Hc only nx+nth wide (tmpc_condense.hpp), which cuts their share of every
+//      sweep by nv/kc and of G'DG by (nv/kc)^2.  The wave-uniform vectors (z, the two directions, their
+//      Psi-coordinates) live in LDS only and are read with broadcast loads.  The normal matrix M = Hs + Gs' D Gs
+//      is accumulated per lane in registers (in one pass, or a few columns of its lower triangle at a time in the
+//      register-lean build) and summed across the wave through an LDS transposition.  The nv x nv solve is
+//      row-distributed: lane i holds row i of M, Gaussian elimination broadcasts the pivot row with v_readlane,
+//      the multipliers stay in place for the corrector's second right-hand side.
 //   4. active-set refinement on W = {lambda_i > s_i}: proximal Newton steps on the
-//      KKT system of the equality-constrained QP (range-space form, S = G_W Hs^-1 G_W'),
-//      accepted only when primal feasible on all rows with non-negative multipliers
+//      KKT system of the equality-constrained QP (range-space form, S = G_W Hs^-1 G_W', factored and solved by the
+//      same readlane elimination on register rows), accepted only when primal feasible on all rows with
+//      non-negative multipliers
 //   5. outputs: u_nom, x_nom[0], (x_bar, u_bar) = Mth theta, optionally x_nom
 //
 // Numerics are float64 throughout: cond(Hs) ~ 3e5 after scaling and the weights
