@@ -165,6 +165,11 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         out = self._solve(x_init, ref)
         return self._unpack(out, batched, "tube tracking MPC")
 
+    def solve(self, x_k, ref):
+        """Alias of `solve_optimization_problem` under the name BASELINE.json's north_star uses (`.solve(x_k, ref)`); the
+        reference itself has no method of this name."""
+        return self.solve_optimization_problem(x_k, ref)
+
     def _is_batched(self, x) -> bool:
         """(nx,) and the reference's column vector (nx,1) are single instances; (B,nx) is a batch."""
         return np.ndim(x) == 2 and np.shape(x) != (self._nx, 1)
@@ -311,3 +316,8 @@ class ExtendedTubeTrackingMPC(TubeTrackingMPC):
         x_nom_0 = None if x_nom is None else x_nom[:, 0]
         packet["x_nom_0"] = x_nom_0
         return packet, x_nom_0
+
+
+# BASELINE.json's north_star speaks of "TubeTrackingMPCOverLossyNet"; the reference has no such class (the lossy-network loop is a
+# script-level composition of MPC + Estimator + ConsistentActuator).  The name is provided as an alias.
+TubeTrackingMPCOverLossyNet = TubeTrackingMPC
