@@ -207,6 +207,18 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
 #define TMPC_PLANT_CARTPOLE 1
 int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps);
 
+/*
+ * Plant-side actuator simulated by tmpc_mc_run.  TMPC_ACTUATOR_CONSISTENT (default): ConsistentActuator with nominal
+ * model and ancillary feedback (SmartActuator.py:125-231), the remote tube MPC's actuator.  TMPC_ACTUATOR_SMART: the plain
+ * SmartActuator (SmartActuator.py:11-123) the reference pairs with the non-robust TrackingMPC (results_linear_system.py:
+ * 198-205, 262-287): no nominal model, terminal law on the measured state, the plant packet carries the measured state.
+ * With it a trajectory whose solve is infeasible stops (the reference sets track_feasible = False, :268-270): its err2
+ * becomes NaN, its x_final the last state reached, and not_optimal counts the one failed solve.
+ */
+#define TMPC_ACTUATOR_CONSISTENT 0
+#define TMPC_ACTUATOR_SMART      1
+int tmpc_mc_set_actuator(tmpc_handle *h, int kind);
+
 /* Block until everything enqueued on the handle's stream has finished. */
 int tmpc_synchronize(tmpc_handle *h);
 

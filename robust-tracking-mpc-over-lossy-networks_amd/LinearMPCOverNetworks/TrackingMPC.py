@@ -22,6 +22,8 @@ from .TubeTrackingMPC import TubeTrackingMPC
 
 class TrackingMPC(TubeTrackingMPC):
 
+    _smart_actuator = True             # results_linear_system.py:198-205: R-MPC runs with Estimator + SmartActuator
+
     def setup_optimization(self):
         """TrackingMPC.py:187-192."""
         self._Xc, self._Uc = self._X, self._U            # no tightening: the nominal prediction IS the prediction

@@ -41,6 +41,7 @@ _STATUS_TEXT = {0: "optimal", 1: "optimal_inaccurate", 2: "infeasible", 3: "solv
 class TubeTrackingMPC(TubeRegulatorMPC):
 
     _VARIANTS = 1
+    _smart_actuator = False            # closed loop: ConsistentActuator (tube MPC); TrackingMPC pairs with the plain SmartActuator
 
     def __init__(self, A, B, Q, R, N: int, lambda_param: float = 0.99999):
         super().__init__(A, B, Q, R, N)
@@ -218,7 +219,9 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         if self._handle is None:
             raise RuntimeError("setup_optimization() has not been called")
         _native.mc_set_plant(self._handle, plant)        # None: the linear model; 'cartpole': the nonlinear cart-pole (RK4, 500 Hz)
-        return _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=self._Z, extended=extended)
+        _native.mc_set_actuator(self._handle, self._smart_actuator)
+        return _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
+                              extended=extended)
 
     # ------------------------------------------------------------------ accessors
     def set_ancillary_controller_gain(self, K_ancillary):

@@ -89,6 +89,8 @@ def lib():
         L.tmpc_get_kernel_path.restype = C.c_int
         L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 5
         L.tmpc_mc_run.restype = C.c_int
+        L.tmpc_mc_set_actuator.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_mc_set_actuator.restype = C.c_int
         L.tmpc_mc_set_plant.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
         L.tmpc_mc_set_plant.restype = C.c_int
         L.tmpc_synchronize.argtypes = [C.c_void_p]
@@ -259,6 +261,12 @@ def get_kernel_path(h: Handle, variant: int = 0) -> str:
     if code < 0:
         raise RuntimeError("tmpc_get_kernel_path failed")
     return {v: k for k, v in KERNEL_PATHS.items()}[code]
+
+
+def mc_set_actuator(h: Handle, smart: bool):
+    """include/tmpc.h: tmpc_mc_set_actuator (False: consistent actuator, True: plain smart actuator of the R-MPC loop)."""
+    if lib().tmpc_mc_set_actuator(h.ptr, 1 if smart else 0) != 0:
+        raise RuntimeError(h.error())
 
 
 def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):

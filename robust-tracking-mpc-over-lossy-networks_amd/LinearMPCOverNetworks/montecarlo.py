@@ -138,6 +138,49 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
                 consistent_estimate_error=consistent_err, x_final=x)
 
 
+def run_remote_tracking_mpc(packets_fn, A, B, K, N, p_loss, ref, th_u, ga_u, w, x0=None):
+    """Closed loop of the non-robust comparator (R-MPC) over the lossy network: TrackingMPC + Estimator + plain
+    SmartActuator (results_linear_system.py:198-205, 262-287).  A trajectory whose solve is infeasible stops there
+    (track_feasible = False, :268-270) and reports a NaN tracking error (:297).  Same conventions as
+    run_remote_tube_mpc otherwise."""
+    from .Estimator import BatchedEstimator
+    from .SmartActuator import BatchedConsistentActuator
+    A = np.asarray(A, dtype=np.float64)
+    Bm = np.asarray(B, dtype=np.float64)
+    nb, T = th_u.shape
+    nx = A.shape[0]
+    p_loss = np.asarray(p_loss, dtype=np.float64).reshape(nb)
+    x = np.zeros((nb, nx)) if x0 is None else np.array(x0, dtype=np.float64).reshape(nb, nx)
+    est = BatchedEstimator(A, Bm, K, x, N)
+    act = BatchedConsistentActuator(A, Bm, K, np.zeros_like(np.atleast_2d(K)), x)     # no nominal model: x_nom := x each step
+    err2 = np.zeros(nb)
+    dead = np.zeros(nb, dtype=bool)
+    not_optimal = np.zeros(nb, dtype=np.int32)
+    U_prev = None
+    for t in range(T):
+        theta = np.where(th_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)
+        r_t = np.zeros((nb, nx))
+        r_t[:, 0] = ref[t]
+        q_t = est.get_qt()
+        U_t, _, status = packets_fn(est.get_estimate(), r_t)
+        newly = ~dead & (status >= 2)
+        not_optimal += (~dead & (status != 0))
+        dead |= newly
+        U_t = np.where(np.isfinite(U_t), U_t, 0.0 if U_prev is None else U_prev)       # keeps the frozen trajectories' state machines NaN-free
+        U_prev = U_t
+        est.store(U_t)
+        act.x_nom = x.copy()
+        u, pkt = act.process(U_t, q_t, x, theta)
+        pkt = {"x_t": x.copy(), "s_t": pkt["s_t"]}
+        err2 += np.where(dead, 0.0, (x[:, 0] - ref[t]) ** 2 + np.sum(x[:, 1:] ** 2, axis=1))
+        x = np.where(dead[:, None], x, x @ A.T + u @ Bm.T + w[:, t])
+        gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)
+        est.update(pkt, gamma)
+    te = np.sqrt(err2) / T
+    te[dead] = np.nan
+    return dict(tracking_error=te, not_optimal=not_optimal, infeasible=dead, x_final=x)
+
+
 def plant_callable(plant):
     """'cartpole' -> the numpy counterpart of the device plant (workloads.cartpole_step); callables pass through."""
     if callable(plant):

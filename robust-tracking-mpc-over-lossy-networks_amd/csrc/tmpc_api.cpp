@@ -52,6 +52,7 @@ struct tmpc_handle {
     int32_t *ws_stat = nullptr, *ws_it = nullptr;
     std::vector<double> hA, hB, hK, hKanc;   // host copies for the closed-loop entry point
     int plant = TMPC_PLANT_LINEAR, plant_substeps = 10;
+    int actuator = TMPC_ACTUATOR_CONSISTENT;
     double plant_par[7] = {0, 0, 0, 0, 0, 0, 0};
     int kernel_path = TMPC_PATH_AUTO;
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
@@ -487,6 +488,13 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
     return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;
 }
 
+int tmpc_mc_set_actuator(tmpc_handle *h, int kind) {
+    if (!h) return TMPC_E_INVALID;
+    if (kind != TMPC_ACTUATOR_CONSISTENT && kind != TMPC_ACTUATOR_SMART) { h->err = "tmpc_mc_set_actuator: unknown actuator"; return TMPC_E_INVALID; }
+    h->actuator = kind;
+    return TMPC_OK;
+}
+
 int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps) {
     if (!h) return TMPC_E_INVALID;
     if (kind == TMPC_PLANT_LINEAR) { h->plant = kind; return TMPC_OK; }
@@ -530,7 +538,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
         tmpc::McModel m{};
         tmpc::McState st{};
         m.nx = h->nx; m.nu = h->nu; m.N = h->N; m.extended = extended ? 1 : 0; m.rZ = rZ;
-        m.plant = h->plant; m.substeps = h->plant_substeps;
+        m.plant = h->plant; m.substeps = h->plant_substeps; m.smart = h->actuator == TMPC_ACTUATOR_SMART ? 1 : 0;
         for (int i = 0; i < 7; ++i) m.par[i] = h->plant_par[i];
         int r2;
         if ((r2 = up(h->hA.data(), nx * nx * 8, reinterpret_cast<const void **>(&m.A)))) return r2;
@@ -552,7 +560,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             {reinterpret_cast<void **>(&st.q_act), b * 4, 0}, {reinterpret_cast<void **>(&st.s), b * 4, 0},
             {reinterpret_cast<void **>(&st.Theta), b * 4, 0}, {reinterpret_cast<void **>(&st.last_lost), b * 4, 0xFF},
             {reinterpret_cast<void **>(&st.tube_viol), b * 4, 0}, {reinterpret_cast<void **>(&st.not_optimal), b * 4, 0},
-            {reinterpret_cast<void **>(&st.gamma), b, 1}};
+            {reinterpret_cast<void **>(&st.gamma), b, 1}, {reinterpret_cast<void **>(&st.dead), b, 0}};
         for (auto &a : arrays) {
             if ((r2 = dalloc(a.bytes, a.p))) return r2;
             HIP_TRY(h, hipMemsetAsync(*a.p, a.fill, a.bytes, h->stream));        // 0xFF bytes = -1 for last_lost; gamma = 1

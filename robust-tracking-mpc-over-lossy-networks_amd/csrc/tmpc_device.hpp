@@ -89,6 +89,7 @@ hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double
 struct McModel {
     int nx, nu, N, extended, rZ;
     int plant, substeps;                 // TMPC_PLANT_*, RK4 steps per sampling period
+    int smart;                           // TMPC_ACTUATOR_SMART: no nominal model, infeasible trajectories stop
     double par[7];                       // cart-pole: M, m, b, I, g, l, Th
     const double *A, *B, *K, *K_anc;     // model and gains (row-major)
     const double *HZ, *hZ;               // tube cross-section Z for the membership check
@@ -101,6 +102,7 @@ struct McState {                         // all [trajectory]-major device arrays
     double *err2, *consistent;           // statistics                                                          [B]
     int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal;
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
+    uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
 };
 hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream);

@@ -53,12 +53,18 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int nx = m.nx, nu = m.nu, N = m.N;
+    if (st.dead[b]) return;                                                              // results_linear_system.py:262
     const double p = st.p_loss[b];
     int theta = (t > 0 && st.th_u[b * T + t] < p) ? 0 : 1;                               // strict <, first packet always arrives
     const int stat = status[b];
     const bool bad = stat >= 2;
     if (stat != 0) st.not_optimal[b] += 1;
     if (bad) theta = 0;            // a failed solve sends nothing (the reference's tube branch would raise here)
+    if (m.smart && bad) {          // R-MPC branch: the trajectory ends here (:268-270), its tracking error is NaN (:297)
+        st.dead[b] = 1;
+        st.err2[b] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
 
     double x[MAXN], xn[MAXN], e[MAXN];
     for (int i = 0; i < nx; ++i) x[i] = st.x[b * nx + i];
@@ -83,7 +89,8 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
         if (m.extended)
             for (int i = 0; i < nx; ++i) st.x_nom[b * nx + i] = x_nom0[b * nx + i];
     }
-    for (int i = 0; i < nx; ++i) { xn[i] = st.x_nom[b * nx + i]; e[i] = x[i] - xn[i]; }
+    // the plain smart actuator has no nominal model: its terminal law and its packet use the measured state
+    for (int i = 0; i < nx; ++i) { xn[i] = m.smart ? x[i] : st.x_nom[b * nx + i]; e[i] = x[i] - xn[i]; }
     const int d = t - st.s[b];
     const bool inside = d < N;
     double un[MAXN], u[MAXN];

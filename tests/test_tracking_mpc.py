@@ -58,3 +58,25 @@ def test_tracking_mpc_parity_and_packets(hip_lib, oracle_lib):
     np.testing.assert_allclose(pkt["U_t"][0, :10], ref["u_nom"][i, :, 0], atol=1e-8)
     np.testing.assert_allclose(pkt["U_t"][0, 10], ref["u_ss"][i, 0] + (mpc._K @ ref["x_ss"][i])[0], atol=1e-8)
     assert mpc.determine_packet(X[j].copy(), R[j].copy(), 4)["U_t"] is None                 # infeasible -> None (results_linear_system.py:268)
+
+
+@pytest.mark.gpu
+def test_rmpc_closed_loop_device_equals_host(hip_lib):
+    """The comparator's closed loop (TrackingMPC + Estimator + plain SmartActuator, results_linear_system.py:198-205,
+    262-287) on the device against the numpy state machines; trajectories that become infeasible stop and report NaN."""
+    from LinearMPCOverNetworks import montecarlo
+    mpc, w = _make(True)
+    nb, T = 96, 60
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(-1, 1, (nb, 2)) * [7.6, 0.6]
+    p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, 3.0 * w["w_bound"], seed=5)       # a rough ride: some leave the feasible set
+    ref = np.where(np.arange(T) < 30, 6.0, -6.0)
+    host = montecarlo.run_remote_tracking_mpc(mpc.determine_packets, w["A"], w["B"], mpc.get_steady_state_controller_gain(), 10,
+                                              p_loss, ref, th, ga, dist, x0=x0)
+    dev = mpc.run_closed_loop(p_loss, ref, th, ga, dist, x0=x0)
+    dead = np.isnan(dev["tracking_error"])
+    assert np.array_equal(dead, host["infeasible"]) and 0 < dead.sum() < nb
+    assert np.array_equal(dev["not_optimal"], host["not_optimal"])
+    np.testing.assert_allclose(dev["tracking_error"][~dead], host["tracking_error"][~dead], atol=1e-10, rtol=0)
+    np.testing.assert_allclose(dev["x_final"], host["x_final"], atol=1e-8, rtol=0)
