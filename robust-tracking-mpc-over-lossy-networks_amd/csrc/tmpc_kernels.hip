@@ -1194,7 +1194,9 @@ hipError_t launch_wpb(const DeviceQP &qp, const WarmStart &warm, int variant_id,
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     int64_t blocks = (B + WPB - 1) / WPB;
-    const int64_t cap = static_cast<int64_t>(n_cu) * (WPB == 8 ? 2 : 4);     // a few workgroups per CU, grid-stride over the batch
+    // one persistent workgroup per CU (the LDS footprint admits no second one): the model is staged once and every wave
+    // fetches its next instance as soon as it is done with the current one (grid-stride over the batch)
+    const int64_t cap = static_cast<int64_t>(n_cu);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((solve_kernel<NV, RD, KC, RC, WARM, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
