@@ -19,3 +19,11 @@ for _ in range(2):
     mpc._solve(X, R, want_traj=False)
     ms = _native.last_kernel_ms(mpc._handle)
     print("B=4096 N=20 kernel ms", ms, "->", 4096 / ms * 1e3, "solves/s")
+
+for path in ("block", "wave"):
+    mpc.set_kernel_path(path)
+    out2 = mpc._solve(S[:, :4], S[:, 4:])
+    print(path, "max |u - oracle|", np.abs(out2["u_nom"] - ref["u_nom"]).max())
+    for _ in range(2):
+        mpc._solve(X, R, want_traj=False)
+    print("B=4096 N=20", path, "kernel ms", _native.last_kernel_ms(mpc._handle))
