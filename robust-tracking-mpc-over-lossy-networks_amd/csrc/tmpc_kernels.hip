@@ -42,7 +42,6 @@ namespace tmpc {
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int WAVES_PER_BLOCK = 4;
 constexpr int WCAP = 24;          // max rows in the refinement's working set
 constexpr int RED_ROWS_MAX = 16;  // entries per transposition round (12 in the two-waves-per-SIMD build: smaller tile)
 constexpr int RED_STRIDE = 68;    // 64 lanes + a pad after every 16: conflict-free transposed reads
@@ -94,11 +93,6 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
     return __hiloint2double(hi, lo);
 }
-// a wave-uniform value moved to (and from then on kept in) scalar registers: FMAs take it as their
-// one SGPR operand, and the 64-lane copies of z, dz, ... stop occupying vector registers
-__device__ __forceinline__ double uni(double v) {
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
 struct OpSum { __device__ __forceinline__ static double f(double a, double b) { return a + b; } };
 struct OpMin { __device__ __forceinline__ static double f(double a, double b) { return fmin(a, b); } };
 struct OpMax { __device__ __forceinline__ static double f(double a, double b) { return fmax(a, b); } };
@@ -114,13 +108,6 @@ __device__ __forceinline__ double wave_reduce(double v) {
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
 __device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
 __device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
-
-__device__ __forceinline__ double shfl_xor_d(double v, int m) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, m, WAVE);
-    hi = __shfl_xor(hi, m, WAVE);
-    return __hiloint2double(hi, lo);
-}
 
 // Sum each of acc[0..CNT) over the 64 lanes and leave the totals in out[0..CNT) (LDS).
 // Round: 16 entries are written as rows of a [16][RED_STRIDE] LDS tile (lane l at column
@@ -196,17 +183,6 @@ __device__ __forceinline__ void rows_forward(const double (&row)[NV], double &b,
         b = fma(-f, readlane_d(b, k), b);
     }
 }
-// back substitution; x comes out wave-uniform.  (b is destroyed.)
-template <int NV>
-__device__ __forceinline__ void rows_backsub(const double (&row)[NV], double b, double dinv, double (&x)[NV]) {
-#pragma unroll
-    for (int i = NV - 1; i >= 0; --i) {
-        const double xi = readlane_d(b * dinv, i);
-        x[i] = xi;
-        b = fma(-row[i], xi, b);      // lanes r < i consume U[r][i]; the others are already done
-    }
-}
-
 // back substitution that leaves x_i on lane i (instead of wave-uniform copies): the caller stores it to LDS,
 // from where the row sweeps read it with broadcast loads -- no 64-lane register copies of dz
 template <int NV>
@@ -403,32 +379,6 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
         }
     }
     wave_reduce_to_lds<KT + KC, SH::RR>(acc, red, csums, lane);
-}
-
-// (G_row . z, G_row . d1[, G_row . d2]) for the row in (slot K, this lane), sharing the row's loads
-template <class SH, int K, bool THREE>
-__device__ __forceinline__ void row_dots(const double *Gt, const double *Hct, const double (&z)[SH::NV], const double (&cz)[SH::KCA],
-                                         const double (&d1)[SH::NV], const double (&c1)[SH::KCA], const double (&d2)[SH::NV],
-                                         const double (&c2)[SH::KCA], int lane, double &o0, double &o1, double &o2) {
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-    if constexpr (K < SH::RD) {
-        const int r = lane + K * WAVE;
-#pragma unroll
-        for (int j = 0; j < SH::NV; ++j) {
-            const double g = Gt[j * SH::NDP + r];
-            t0 += g * z[j]; t1 += g * d1[j];
-            if (THREE) t2 += g * d2[j];
-        }
-    } else {
-        const int rc = lane + (K - SH::RD) * WAVE;
-#pragma unroll
-        for (int a = 0; a < SH::KC; ++a) {
-            const double g = Hct[a * SH::NCCP + rc];
-            t0 += g * cz[a]; t1 += g * c1[a];
-            if (THREE) t2 += g * c2[a];
-        }
-    }
-    o0 = t0; o1 = t1; o2 = t2;
 }
 
 template <int NV, int RD, int KC, int RC, bool WARM, int WPB>
