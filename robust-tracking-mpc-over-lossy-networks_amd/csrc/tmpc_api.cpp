@@ -205,6 +205,10 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     v.db.nd = c.nc; v.db.ncc = 0; v.db.kc = 0;
     v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = nullptr;
     v.bq.ncp = ncp;
+    // the Z rows of a free initial state touch x_0 only: the block kernel treats them as a narrow class when there are many
+    v.bq.nz4 = (c.off_x0 >= 0 && c.nz >= 256) ? (c.nz / 4) * 4 : 0;
+    v.bq.zx0 = c.off_x0 >= 0 ? c.off_x0 : 0;
+    v.bq.znx = nx;
     if ((rc = upload(h, v, Grm.data(), Grm.size(), &v.bq.Grm))) return rc;
     if ((rc = upload(h, v, Gcm.data(), Gcm.size(), &v.bq.Gcm))) return rc;
     if ((rc = upload(h, v, GH.data(), GH.size(), &v.bq.GHrm))) return rc;

@@ -84,8 +84,12 @@ __device__ __forceinline__ double block_reduce1(double a, double *red, int wave,
 
 // G_row(r) . v for the thread's row: column-major copy, v in LDS (broadcast reads).  Eight loads in flight per
 // step: the operands come from L2, the loop is bound by how many of them are outstanding.
-__device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v) {
+__device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v, const BlockQP &bq) {
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    if (r < bq.nz4) {                      // initial-state row: znx columns only
+        for (int a = 0; a < bq.znx; ++a) t0 = fma(Gcm[static_cast<size_t>(bq.zx0 + a) * ncp + r], v[bq.zx0 + a], t0);
+        return t0;
+    }
     int j = 0;
     for (; j + 8 <= nv; j += 8) {
         double g[8];
@@ -101,11 +105,11 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
 // out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
 template <int T>
 __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
-                                            double *parts, double *out_a, double *out_b, int tid) {
+                                            double *parts, double *out_a, double *out_b, int tid, const BlockQP &bq) {
     constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS;
     const int j = tid % NVP, part = tid / NVP;
     double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
-    int r = part;
+    int r = bq.nz4 + part;                 // general rows; the initial-state rows [0, nz4) follow below
     for (; r + 7 * PARTS < nc; r += 8 * PARTS) {           // eight rows in flight (L2 latency, see row_dot)
         double g[8], xa[8], xb[8];
 #pragma unroll
@@ -136,12 +140,46 @@ __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int 
         out_b[tid] = sb;
     }
     __syncthreads();
+    if (bq.nz4 > 0) {
+        // initial-state rows: znx (<= 16) columns; the 256 threads are zpad column slots x (256 / zpad) row parts, four
+        // rows in flight per thread
+        const int zpad = bq.znx <= 4 ? 4 : (bq.znx <= 8 ? 8 : 16), ZP = BT / zpad;
+        const int a = tid % zpad, rp2 = tid / zpad;
+        double sa0 = 0.0, sb0 = 0.0, sa1 = 0.0, sb1 = 0.0;
+        if (a < bq.znx) {
+            const double *gcol = Grm + bq.zx0 + a;
+            int r2 = rp2;
+            for (; r2 + 3 * ZP < bq.nz4; r2 += 4 * ZP) {
+                const double g0 = gcol[static_cast<size_t>(r2) * NVP], g1 = gcol[static_cast<size_t>(r2 + ZP) * NVP];
+                const double g2 = gcol[static_cast<size_t>(r2 + 2 * ZP) * NVP], g3 = gcol[static_cast<size_t>(r2 + 3 * ZP) * NVP];
+                const double x0 = va[r2], x1 = va[r2 + ZP], x2 = va[r2 + 2 * ZP], x3 = va[r2 + 3 * ZP];
+                const double y0 = vb[r2], y1 = vb[r2 + ZP], y2 = vb[r2 + 2 * ZP], y3 = vb[r2 + 3 * ZP];
+                sa0 = fma(g0, x0, sa0); sb0 = fma(g0, y0, sb0); sa1 = fma(g1, x1, sa1); sb1 = fma(g1, y1, sb1);
+                sa0 = fma(g2, x2, sa0); sb0 = fma(g2, y2, sb0); sa1 = fma(g3, x3, sa1); sb1 = fma(g3, y3, sb1);
+            }
+            for (; r2 < bq.nz4; r2 += ZP) {
+                const double g = gcol[static_cast<size_t>(r2) * NVP];
+                sa0 = fma(g, va[r2], sa0);
+                sb0 = fma(g, vb[r2], sb0);
+            }
+        }
+        parts[tid] = sa0 + sa1;
+        parts[BT + tid] = sb0 + sb1;
+        __syncthreads();
+        if (tid < bq.znx) {
+            double ta = 0.0, tb = 0.0;
+            for (int q = 0; q < ZP; ++q) { ta += parts[q * zpad + tid]; tb += parts[BT + q * zpad + tid]; }
+            out_a[bq.zx0 + tid] += ta;
+            out_b[bq.zx0 + tid] += tb;
+        }
+        __syncthreads();
+    }
 }
 
 // Tiles of the lower triangle of G'DG owned by tile group GI (tile rows RA = GI and RB = T-1-GI),
 // accumulated over the k-steps (4 rows each) rpart, rpart + RSPLIT, ... and added into M (LDS).
 template <int T, int GI>
-__device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int nsteps, int rpart,
+__device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int ks0, int nsteps, int rpart,
                                           double *M, int lane) {
     using SH = BShape<T>;
     constexpr int NVP = SH::NVP, LDM = SH::LDM, RS = SH::RSPLIT;
@@ -170,7 +208,7 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
             dv[u] = in ? dvec[row] : 0.0;
         }
     };
-    int ks = rpart;
+    int ks = ks0 + rpart;                       // k-steps below ks0 belong to the initial-state rows (handled apart)
     load_group(ks, cur, dcur);                  // unconditional (indices are clamped inside): a branch around the
     for (; ks < nsteps; ks += RS * U) {         // prefetch makes the compiler wait for ALL loads before the MFMAs
         load_group(ks + RS * U, nxt, dnxt);
@@ -211,21 +249,64 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
     }
 }
 
+// M += Gz' D Gz for the initial-state rows [0, nz4): they touch the znx columns of x_0 only, so their share of G'DG is a
+// znx x znx block (10 entries for the cart-pole instead of a pass of all 16-wide tiles over 850 rows).  Thread (pair p of
+// the lower triangle, row part q) sums d_r g_ra g_rb over its rows; the parts meet in LDS.
 template <int T>
-__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, int nsteps, double *M,
+__device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm, const double *__restrict__ dvec, const BlockQP &bq,
+                                                  double *M, double *parts, int tid) {
+    if (bq.nz4 <= 0) return;
+    constexpr int NVP = BShape<T>::NVP, LDM = BShape<T>::LDM;
+    const int P = bq.znx * (bq.znx + 1) / 2;           // <= 136
+    const int Q = BT / P;
+    const int p = tid % P, q = tid / P;
+    int a = 0, rem = p;
+    while (rem > a) { rem -= a + 1; ++a; }             // p -> (a, b), b <= a
+    const int b = rem;
+    double t0 = 0.0, t1 = 0.0;
+    if (q < Q) {
+        int r = q;
+        for (; r + 3 * Q < bq.nz4; r += 4 * Q) {            // four rows in flight
+            const double *g0 = Grm + static_cast<size_t>(r) * NVP + bq.zx0, *g1 = Grm + static_cast<size_t>(r + Q) * NVP + bq.zx0;
+            const double *g2 = Grm + static_cast<size_t>(r + 2 * Q) * NVP + bq.zx0, *g3 = Grm + static_cast<size_t>(r + 3 * Q) * NVP + bq.zx0;
+            const double d0 = dvec[r], d1 = dvec[r + Q], d2 = dvec[r + 2 * Q], d3 = dvec[r + 3 * Q];
+            const double a0 = g0[a], b0 = g0[b], a1 = g1[a], b1 = g1[b], a2 = g2[a], b2 = g2[b], a3 = g3[a], b3 = g3[b];
+            t0 = fma(d0 * a0, b0, t0); t1 = fma(d1 * a1, b1, t1);
+            t0 = fma(d2 * a2, b2, t0); t1 = fma(d3 * a3, b3, t1);
+        }
+        for (; r + Q < bq.nz4; r += 2 * Q) {
+            const double *g0 = Grm + static_cast<size_t>(r) * NVP + bq.zx0, *g1 = Grm + static_cast<size_t>(r + Q) * NVP + bq.zx0;
+            t0 = fma(dvec[r] * g0[a], g0[b], t0);
+            t1 = fma(dvec[r + Q] * g1[a], g1[b], t1);
+        }
+        if (r < bq.nz4) { const double *g0 = Grm + static_cast<size_t>(r) * NVP + bq.zx0; t0 = fma(dvec[r] * g0[a], g0[b], t0); }
+    }
+    __syncthreads();
+    parts[tid] = t0 + t1;
+    __syncthreads();
+    if (tid < P) {
+        double v = 0.0;
+        for (int k = 0; k < Q; ++k) v += parts[k * P + tid];
+        M[(bq.zx0 + a) * LDM + bq.zx0 + b] += v;
+    }
+    __syncthreads();
+}
+
+template <int T>
+__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, int ks0, int nsteps, double *M,
                                         int wave, int lane) {
     constexpr int G = BShape<T>::G;
     const int g = wave % G, rpart = wave / G;
     if constexpr (G == 1) {
-        gdg_group<T, 0>(Grm, dvec, nsteps, rpart, M, lane);
+        gdg_group<T, 0>(Grm, dvec, ks0, nsteps, rpart, M, lane);
     } else if constexpr (G == 2) {
-        if (g == 0) gdg_group<T, 0>(Grm, dvec, nsteps, rpart, M, lane);
-        else gdg_group<T, 1>(Grm, dvec, nsteps, rpart, M, lane);
+        if (g == 0) gdg_group<T, 0>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        else gdg_group<T, 1>(Grm, dvec, ks0, nsteps, rpart, M, lane);
     } else {
-        if (g == 0) gdg_group<T, 0>(Grm, dvec, nsteps, rpart, M, lane);
-        else if (g == 1) gdg_group<T, 1>(Grm, dvec, nsteps, rpart, M, lane);
-        else if (g == 2) gdg_group<T, 2>(Grm, dvec, nsteps, rpart, M, lane);
-        else gdg_group<T, 3>(Grm, dvec, nsteps, rpart, M, lane);
+        if (g == 0) gdg_group<T, 0>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        else if (g == 1) gdg_group<T, 1>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        else if (g == 2) gdg_group<T, 2>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        else gdg_group<T, 3>(Grm, dvec, ks0, nsteps, rpart, M, lane);
     }
 }
 
@@ -435,7 +516,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
         __syncthreads();
         double smin_l = INFINITY;
         for (int r = tid; r < ncp; r += BT) {
-            const double gz = row_dot(Gcm, ncp, nv, r, zv);
+            const double gz = row_dot(Gcm, ncp, nv, r, zv, bq);
             const double sv = h_[r] - gz;
             gz_[r] = gz;
             s_[r] = sv;
@@ -493,7 +574,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
             for (int j = 0; j < NVP; ++j) v += qp.Hs[j * NVP + tid] * zv[j];
                         cgv[tid] = v;
                     }
-                    gt_products<T>(Grm, nc, lam_, v1_, parts, glv, tv, tid);
+                    gt_products<T>(Grm, nc, lam_, v1_, parts, glv, tv, tid, bq);
                     double rdn = 0.0, obj = 0.0, gln = 0.0;
                     if (tid < NVP) {
                         const double cgj = cgv[tid], qj = qv[tid];
@@ -526,7 +607,8 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         }
                         __syncthreads();
                         BSTAMP(3);
-                        gdg_all<T>(Grm, d_, nsteps, big, wave, lane);
+                        gdg_all<T>(Grm, d_, bq.nz4 / 4, nsteps, big, wave, lane);
+                        zblock_accumulate<T>(Grm, d_, bq, big, parts, tid);
                         BSTAMP(4);
                         spd = block_chol<T>(big, LDM, nv, dinv, red + 16, tid);
                         BSTAMP(5);
@@ -544,7 +626,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
                     for (int r = tid; r < ncp; r += BT) {
                         const bool valid = r < nc;
-                        const double gd = row_dot(Gcm, ncp, nv, r, dzav);
+                        const double gd = row_dot(Gcm, ncp, nv, r, dzav, bq);
                         const double sv = s_[r], lv = lam_[r], rp = rp_[r], d = d_[r];
                         const double rs = valid ? fast_rcp(sv) : 0.0;
                         const double dsa = valid ? (-rp - gd) : 0.0;
@@ -566,7 +648,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     const double smu = sigma * mu;
                     BSTAMP(7);
                     // ---- P6: corrector right-hand side and solve
-                    gt_products<T>(Grm, nc, c1_, rs_, parts, tv, uv, tid);
+                    gt_products<T>(Grm, nc, c1_, rs_, parts, tv, uv, tid, bq);
                     if (tid < NVP) cgv[tid] = rhsv[tid] + tv[tid] - smu * uv[tid];
                     __syncthreads();
                     if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, cgv, dzv, lane, NVP);
@@ -579,7 +661,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     double rho = 0.0;
                     for (int r = tid; r < ncp; r += BT) {
                         const bool valid = r < nc;
-                        const double gd = row_dot(Gcm, ncp, nv, r, dzv);
+                        const double gd = row_dot(Gcm, ncp, nv, r, dzv, bq);
                         const double sv = s_[r], lv = lam_[r], rp = rp_[r], rs = rs_[r];
                         const double dsk = valid ? (-rp - gd) : 0.0;
                         const double rc = sv * lv + w_[r] - smu;
@@ -706,7 +788,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         for (int r = tid; r < ncp; r += BT) {
                             const bool valid = r < nc;
                             const double hk = h_[r];
-                            const double rr = row_dot(Gcm, ncp, nv, r, zpv) - hk;
+                            const double rr = row_dot(Gcm, ncp, nv, r, zpv, bq) - hk;
                             rr_[r] = rr;
                             const bool in = inW_[r] != 0;
                             const double hi = fmax(fabs(hk), 1.0);

@@ -294,6 +294,9 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         for (int r : keep) ((compact && rowblk[r] == 1) ? term_rows : dense_rows).push_back(r);
         keep = dense_rows;
         keep.insert(keep.end(), term_rows.begin(), term_rows.end());
+        c.nz = 0;
+        if (!fixed)
+            for (int r : dense_rows) { if (r < rz) ++c.nz; else break; }      // they come first in the reference's order
         c.nd = static_cast<int>(dense_rows.size());
         c.ncc = static_cast<int>(term_rows.size());
         c.kc = compact ? kT : 0;

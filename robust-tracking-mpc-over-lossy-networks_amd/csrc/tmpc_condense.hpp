@@ -51,6 +51,7 @@ struct Condensed {
     // (TubeTrackingMPC.py:149) acts on [x_N; x_bar; u_bar] only, i.e. on kc = nx + nth (+ nu)
     // combinations of z, so its rows have rank kc << nv.  ncc == 0 when the block is kept dense.
     int nd = 0, ncc = 0, kc = 0;
+    int nz = 0;        // the first nz rows are the initial-state rows Hz (x_k - x_0) <= hz: they act on the x_0 block of z only
     Mat Psi;     // kc x nv, scaled with Dv
     Mat Hc;      // ncc x kc, rows scaled like Gs
 };

@@ -56,6 +56,7 @@ struct WarmStart {
 // Block path (tmpc_block.hip): all rows dense, row order of Condensed::Gs, nv padded to 16 * tiles
 struct BlockQP {
     int ncp;              // padded row count (multiple of 64)
+    int nz4, zx0, znx;    // rows [0, nz4) act on columns [zx0, zx0 + znx) only (initial-state rows; nz4 = 0: no such block)
     const double *Grm;    // [ncp][NVP]  scaled G, row-major, zero padded (MFMA operands, G'v passes)
     const double *Gcm;    // [NVP][ncp]  the same, column-major (thread-per-row products)
     const double *GHrm;   // [ncp][NVP]  G * Hs^-1, row-major (refinement: S = G_W Hs^-1 G_W')
