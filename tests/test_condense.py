@@ -131,3 +131,29 @@ def test_condensed_objective_and_constraints_equal_sparse_ones(hip_lib):
         cands = [f(traj(u1, s * th_lib)) - f(v0) for s in (1.0, -1.0)]
         assert min(abs(fz - cands[0]), abs(fz - cands[1])) <= 1e-9 * max(1.0, abs(fz))
     hip_lib.destroy(h)
+
+
+def test_closed_loop_setters_validate_their_arguments(hip_lib):
+    """tmpc_mc_set_plant / tmpc_mc_set_actuator / tmpc_set_kernel_path on a host-only handle: argument errors come back as
+    codes + message; tmpc_mc_run itself refuses without a device."""
+    import ctypes as C
+    mpc, _ = common.make_mpc("cartpole", 10, True)
+    h = hip_lib.create(mpc._problem_dict(), device=-1)
+    L = hip_lib.lib()
+    assert L.tmpc_mc_set_actuator(h.ptr, 7) == -1 and b"actuator" in L.tmpc_last_error(h.ptr)
+    assert L.tmpc_mc_set_actuator(h.ptr, 1) == 0 and L.tmpc_mc_set_actuator(h.ptr, 0) == 0
+    assert L.tmpc_mc_set_plant(h.ptr, 1, None, 10) == -1                      # cart-pole plant without parameters
+    par = (C.c_double * 7)(1.0, 0.1, 0.0, 0.001, 9.8, 0.5, 0.02)
+    assert L.tmpc_mc_set_plant(h.ptr, 1, par, 0) == -1                         # substeps >= 1
+    assert L.tmpc_mc_set_plant(h.ptr, 1, par, 10) == 0 and L.tmpc_mc_set_plant(h.ptr, 0, None, 0) == 0
+    assert L.tmpc_set_kernel_path(h.ptr, 9) == -1
+    one = np.zeros((1, 1))
+    rc = L.tmpc_mc_run(h.ptr, 1, 1, 0, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data, np.zeros((1, 1, 4)).ctypes.data,
+                       None, None, None, 0, None, None, None, None, None)
+    assert rc == -3 and b"GPU" in L.tmpc_last_error(h.ptr)                      # TMPC_E_DEVICE: no CPU path
+    hip_lib.destroy(h)
+    # double integrator: the cart-pole plant needs nx = 4, nu = 1
+    mpc2, _ = common.make_mpc("double_integrator", 5, False)
+    h2 = hip_lib.create(mpc2._problem_dict(), device=-1)
+    assert L.tmpc_mc_set_plant(h2.ptr, 1, par, 10) == -1 and b"nx = 4" in L.tmpc_last_error(h2.ptr)
+    hip_lib.destroy(h2)
