@@ -496,12 +496,16 @@ static int polish(const form_t *f, work_t *w) {
                     w->dy[k] = (gz - w->h[w->W[k]]) - gt;
                 }
                 chol_solve(w->S, m, w->dy);
+                double dzn = 0, zn = 1.0;
                 for (int i = 0; i < nv; ++i) {
                     double v = w->t1[i];
                     for (int k = 0; k < m; ++k) v += w->T[i * m + k] * w->dy[k];
                     w->zp[i] -= v;
+                    if (fabs(v) > dzn) dzn = fabs(v);
+                    if (fabs(w->zp[i]) > zn) zn = fabs(w->zp[i]);
                 }
                 for (int k = 0; k < m; ++k) w->y[k] += w->dy[k];
+                if (step >= 1 && dzn <= 1e-14 * zn) break;       /* the step no longer moves the iterate */
             }
         }
         /* verify */

@@ -769,13 +769,19 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                                 if (wave == 0) wave_llt_solve(S, LDSS, m, dinv, dyv, dyv, lane);
                                 __syncthreads();
                                 // zp -= t1 + Hinv G_W' dy ; y += dy
+                                double dzl = 0.0, zl = 1.0;
                                 if (tid < NVP) {
                                     double v = uv[tid];
                                     for (int k = 0; k < m; ++k) v += GHrm[static_cast<size_t>(Widx[k]) * NVP + tid] * dyv[k];
-                                    zpv[tid] -= v;
+                                    const double zn2 = zpv[tid] - v;
+                                    zpv[tid] = zn2;
+                                    dzl = fabs(v);
+                                    zl = fmax(fabs(zn2), 1.0);
                                 }
                                 if (tid < m) yv[tid] += dyv[tid];
-                                __syncthreads();
+                                double dum = 0.0;
+                                block_reduce3<OpMax, OpMax, OpMax>(dzl, zl, dum, red, wave, lane);
+                                if (stp >= 1 && dzl <= 1e-14 * zl) break;        // the step no longer moves the iterate
                             }
                         }
                         // ---- verify: primal feasibility on all rows, sign of y on W
