@@ -676,16 +676,38 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     double shift = 0.0;
                     bool spd = false;
                     for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
+                        if constexpr (SH::DIET) {
+                            // register-lean build: row li of M is formed in a ROLLED loop into LDS (the transposition tile is idle
+                            // here) and read back.  Unrolled, the 14 loads per entry are all hoisted to the top of the block and
+                            // push the live set far past 256 registers (139 instead of 228 spilled registers with this alone).
+                            double *mt = red + li * (NV + 1);
+#pragma unroll 1
+                            for (int j = 0; j < NV; ++j) {
+                                const int lo = li < j ? li : j, hi2 = li < j ? j : li;
+                                double v = Hs[li * NV + j] + (li == j ? shift : 0.0);
+                                if constexpr (RD > 0) v += sums[lo * NV - lo * (lo - 1) / 2 + hi2 - lo];
+                                if constexpr (KC > 0) {
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) {
-                            const int lo = li < j ? li : j, hi2 = li < j ? j : li;
-                            double v = Hs[li * NV + j] + (li == j ? shift : 0.0);
-                            if constexpr (RD > 0) v += sums[lo * NV - lo * (lo - 1) / 2 + hi2 - lo];
-                            if constexpr (KC > 0) {
-#pragma unroll
-                                for (int a = 0; a < KC; ++a) v += Psi[a * NV + li] * Pm[a * NV + j];
+                                    for (int a = 0; a < KC; ++a) v += Psi[a * NV + li] * Pm[a * NV + j];
+                                }
+                                if (lane < NV) mt[j] = v;
                             }
-                            mrow[j] = (lane < NV) ? v : 0.0;
+                            wave_lds_fence();
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) mrow[j] = (lane < NV) ? mt[j] : 0.0;
+                            wave_lds_fence();
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) {
+                                const int lo = li < j ? li : j, hi2 = li < j ? j : li;
+                                double v = Hs[li * NV + j] + (li == j ? shift : 0.0);
+                                if constexpr (RD > 0) v += sums[lo * NV - lo * (lo - 1) / 2 + hi2 - lo];
+                                if constexpr (KC > 0) {
+    #pragma unroll
+                                    for (int a = 0; a < KC; ++a) v += Psi[a * NV + li] * Pm[a * NV + j];
+                                }
+                                mrow[j] = (lane < NV) ? v : 0.0;
+                            }
                         }
                         rhs_i = (lane < NV) ? -cgv[li] - sums[NT + li] : 0.0;
                         double bb = rhs_i;
