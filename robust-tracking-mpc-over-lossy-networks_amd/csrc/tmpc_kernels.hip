@@ -146,11 +146,6 @@ template <> struct Blocks<8>  { static constexpr int n = 1; static constexpr int
 template <> struct Blocks<12> { static constexpr int n = 1; static constexpr int b[4] = {0, 12, 12, 12}; };
 template <> struct Blocks<16> { static constexpr int n = 5; static constexpr int b[6] = {0, 2, 4, 7, 11, 16}; };
 template <> struct Blocks<24> { static constexpr int n = 10; static constexpr int b[11] = {0, 1, 3, 5, 7, 9, 11, 14, 17, 20, 24}; };
-// the register-lean build keeps <= ~40 accumulators per pass
-template <int NV> struct BlocksLean : Blocks<NV> {};
-template <> struct BlocksLean<8>  { static constexpr int n = 2; static constexpr int b[3] = {0, 3, 8}; };
-template <> struct BlocksLean<12> { static constexpr int n = 3; static constexpr int b[4] = {0, 3, 7, 12}; };
-
 // ---- nv x nv solve, rows distributed over lanes.
 // Lane i (< NV) holds row i of the symmetric positive definite M in registers.  Gaussian
 // elimination without pivoting (= LDL'): at step k the pivot row is broadcast with v_readlane
@@ -200,7 +195,7 @@ __device__ __forceinline__ double rows_backsub_lane(const double (&row)[NV], dou
 
 // compile-time description of one kernel instantiation
 // DIET: the build for two waves per SIMD (eight waves per workgroup): at most 256 registers and ~14 KB of LDS per wave,
-// paid for with a smaller transposition tile and the column-blocked accumulation
+// paid for with a smaller transposition tile and a rolled normal-matrix assembly
 template <int NV_, int RD_, int KC_, int RC_, bool DIET_ = false>
 struct Shape {
     static constexpr int NV = NV_, RD = RD_, KC = KC_, RC = RC_;
@@ -340,7 +335,7 @@ __device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double
                                                   const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                                   double (&dd)[SH::RD > 0 ? SH::RD : 1],
                                                   double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
-    using BL = std::conditional_t<SH::DIET, BlocksLean<SH::NV>, Blocks<SH::NV>>;
+    using BL = Blocks<SH::NV>;      // the same blocks in both builds: the accumulators are not what overflows the lean build's registers
     if constexpr (BI < BL::n) {
         sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
         sweep_a_dense_all<SH, BI + 1>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
