@@ -311,3 +311,35 @@ def test_config5_synthetic_n12_m4_N30(hip_lib, oracle_lib):
     np.testing.assert_allclose(out["u_nom"][ok], ref["u_nom"][ok], atol=ATOL_U, rtol=0)
     np.testing.assert_allclose(out["xu_ss"][ok], ref["xu_ss"][ok], atol=ATOL_SS, rtol=0)
     np.testing.assert_allclose(out["x_nom"][ok], ref["x_nom"][ok], atol=1e-8, rtol=0)
+
+
+@pytest.mark.parametrize("name,fixed,horizons", [("cartpole", True, (3, 6, 9, 12, 15)),
+                                                  ("double_integrator", False, (3, 5, 8, 11, 14)),
+                                                  ("double_integrator_darup", False, (4, 7, 10)),
+                                                  ("double_integrator", True, (4, 9, 13))])
+def test_horizon_sweep_covers_the_kernel_shapes(hip_lib, oracle_lib, name, fixed, horizons):
+    """The offline sets do not depend on N, so the horizon can be swept freely: every N lands on some compiled shape of the
+    wave kernel (or on the block kernel) and must reproduce the oracle."""
+    rng = np.random.default_rng(7)
+    seen = set()
+    for N in horizons:
+        mpc, w = common.make_mpc(name, N, fixed, create=True)
+        nv, nc, _ = hip_lib.get_dims(mpc._handle)
+        seen.add((mpc.get_kernel_path(), nv))
+        nx = w["A"].shape[0]
+        if name == "cartpole":
+            idx = rng.integers(0, len(S), 48)
+            X, R = S[idx, :4].copy(), S[idx, 4:].copy()
+            R[:, 0] += rng.uniform(-0.2, 0.2, 48)
+        else:
+            X = rng.uniform(-1, 1, (48, nx)) * [5.0, 0.7]
+            R = np.c_[rng.uniform(-7, 7, 48), np.zeros(48)]
+        ref = Oracle(mpc._problem_dict()).solve(X, R)
+        out = mpc._solve(X, R)
+        assert np.array_equal(out["status"], ref["status"]), (N, out["status"], ref["status"])
+        ok = ref["status"] == 0
+        assert ok.sum() >= 24
+        np.testing.assert_allclose(out["u_nom"][ok], ref["u_nom"][ok], atol=ATOL_U, rtol=0, err_msg=f"N={N}")
+        np.testing.assert_allclose(out["xu_ss"][ok], ref["xu_ss"][ok], atol=ATOL_SS, rtol=0, err_msg=f"N={N}")
+        np.testing.assert_allclose(out["x_nom"][ok], ref["x_nom"][ok], atol=1e-8, rtol=0, err_msg=f"N={N}")
+    assert len(seen) >= 2
