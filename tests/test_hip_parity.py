@@ -314,6 +314,7 @@ def test_config5_synthetic_n12_m4_N30(hip_lib, oracle_lib):
 
 
 @pytest.mark.parametrize("name,fixed,horizons", [("cartpole", True, (3, 6, 9, 12, 15)),
+                                                  ("cartpole", True, (17, 20, 23, 26)),
                                                   ("double_integrator", False, (3, 5, 8, 11, 14)),
                                                   ("double_integrator_darup", False, (4, 7, 10)),
                                                   ("double_integrator", True, (4, 9, 13))])
