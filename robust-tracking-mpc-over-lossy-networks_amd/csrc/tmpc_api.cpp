@@ -51,6 +51,9 @@ struct tmpc_handle {
     double *ws_s = nullptr, *ws_lam = nullptr, *ws_z = nullptr;
     int32_t *ws_stat = nullptr, *ws_it = nullptr;
     std::vector<double> hA, hB, hK, hKanc;   // host copies for the closed-loop entry point
+    // closed-loop state lives in one grow-only arena (25 hipMalloc / hipFree per call cost several milliseconds)
+    char *mc_arena = nullptr;
+    size_t mc_arena_bytes = 0;
     int plant = TMPC_PLANT_LINEAR, plant_substeps = 10;
     int actuator = TMPC_ACTUATOR_CONSISTENT;
     double plant_par[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -420,7 +423,7 @@ void tmpc_destroy(tmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
     {
-        void *wsp[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it, h->blk_ws};
+        void *wsp[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it, h->blk_ws, h->mc_arena};
         for (void *q2 : wsp) if (q2) (void)hipFree(q2);
     }
     for (int k = 0; k < 2; ++k)
@@ -524,10 +527,23 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     int rc = ensure_staging(h, B);
     if (rc) return rc;
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
-    std::vector<void *> tmp;
+    // upper bound of what the carve-outs below need (each rounded up to 256 B)
+    const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + 2 * t_ + t_ * nx)) +
+                        8 * b * (6 * nx + (N + 1) * nu + nu + 2) + 4 * b * 7 + 2 * b;
+    if (need > h->mc_arena_bytes) {
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        if (h->mc_arena) (void)hipFree(h->mc_arena);
+        h->mc_arena = nullptr;
+        h->mc_arena_bytes = 0;
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->mc_arena), need));
+        h->mc_arena_bytes = need;
+    }
+    size_t arena_off = 0;
     auto dalloc = [&](size_t bytes, void **out) -> int {
-        HIP_TRY(h, hipMalloc(out, bytes ? bytes : 8));
-        tmp.push_back(*out);
+        const size_t sz = ((bytes ? bytes : 8) + 255) / 256 * 256;
+        if (arena_off + sz > h->mc_arena_bytes) { h->err = "tmpc_mc_run: internal arena too small"; return TMPC_E_NOMEM; }
+        *out = h->mc_arena + arena_off;
+        arena_off += sz;
         return TMPC_OK;
     };
     auto up = [&](const void *src, size_t bytes, const void **out) -> int {
@@ -559,7 +575,8 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             {reinterpret_cast<void **>(&st.x), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.x_hat), b * nx * 8, 0},
             {reinterpret_cast<void **>(&st.x_nom), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.Ubuf), b * (N + 1) * nu * 8, 0},
             {reinterpret_cast<void **>(&st.u_latest0), b * nu * 8, 0}, {reinterpret_cast<void **>(&st.x_nom0_latest), b * nx * 8, 0},
-            {reinterpret_cast<void **>(&st.ref_k), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.err2), b * 8, 0},
+            {reinterpret_cast<void **>(&st.ref_k), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.e_buf), b * nx * 8, 0},
+            {reinterpret_cast<void **>(&st.err2), b * 8, 0},
             {reinterpret_cast<void **>(&st.consistent), b * 8, 0}, {reinterpret_cast<void **>(&st.q_est), b * 4, 0},
             {reinterpret_cast<void **>(&st.q_act), b * 4, 0}, {reinterpret_cast<void **>(&st.s), b * 4, 0},
             {reinterpret_cast<void **>(&st.Theta), b * 4, 0}, {reinterpret_cast<void **>(&st.last_lost), b * 4, 0xFF},
@@ -579,6 +596,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it);
             if (r3) return r3;
             HIP_TRY(h, tmpc::launch_mc_post(m, st, t, T, B, ref[t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->stream));
+            HIP_TRY(h, tmpc::launch_mc_tube(m, st, B, h->stream));
         }
         if (err2) HIP_TRY(h, hipMemcpyAsync(err2, st.err2, b * 8, hipMemcpyDeviceToHost, h->stream));
         if (tube_viol) HIP_TRY(h, hipMemcpyAsync(tube_viol, st.tube_viol, b * 4, hipMemcpyDeviceToHost, h->stream));
@@ -590,7 +608,6 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     };
     rc = run();
     if (rc != TMPC_OK) (void)hipStreamSynchronize(h->stream);
-    for (void *q2 : tmp) (void)hipFree(q2);
     return rc;
 }
 

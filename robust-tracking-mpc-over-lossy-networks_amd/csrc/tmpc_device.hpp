@@ -100,6 +100,7 @@ struct McState {                         // all [trajectory]-major device arrays
     double *Ubuf;                        // sequence buffered by the actuator                                  [B][N+1][nu]
     double *u_latest0, *x_nom0_latest;   // first input / x_nom_0 of the last sequence sent                    [B][nu], [B][nx]
     double *ref_k;                       // reference handed to the solve                                       [B][nx]
+    double *e_buf;                       // x_t - x_nom_t of the current step, for the tube membership kernel    [B][nx]
     double *err2, *consistent;           // statistics                                                          [B]
     int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal;
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
@@ -107,6 +108,7 @@ struct McState {                         // all [trajectory]-major device arrays
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
 };
 hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream);
+hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStream_t stream);
 hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
                           const double *x_nom0, const double *xu_ss, const int32_t *status, hipStream_t stream);
 

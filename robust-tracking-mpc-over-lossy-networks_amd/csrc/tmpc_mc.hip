@@ -108,13 +108,9 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
         double a = (x[0] - ref_t) * (x[0] - ref_t);
         for (int i = 1; i < nx; ++i) a += x[i] * x[i];
         st.err2[b] += a;
-        bool out = false;
-        for (int r = 0; r < m.rZ; ++r) {
-            double v = -m.hZ[r];
-            for (int i = 0; i < nx; ++i) v += m.HZ[r * nx + i] * e[i];
-            out = out || (v > 1e-7);                            // polytope's abs_tol
-        }
-        if (out) st.tube_viol[b] += 1;
+        // x_t - x_nom_t in Z (:258) is checked by mc_tube_kernel (rZ rows x nx columns per trajectory: too long a loop for
+        // one thread of this kernel, which only has a wave's worth of parallelism per 64 trajectories)
+        for (int i = 0; i < nx; ++i) st.e_buf[b * nx + i] = e[i];
     }
     // ---- plant and nominal model
     double xp[MAXN], xnp[MAXN];
@@ -174,7 +170,30 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     st.gamma[b] = static_cast<uint8_t>(gamma);
 }
 
+// one workgroup per trajectory: the rZ rows of Z are spread over the threads
+__global__ void mc_tube_kernel(const McModel m, const McState st, const int64_t B) {
+    const int64_t b = blockIdx.x;
+    if (b >= B || st.dead[b]) return;
+    const int nx = m.nx;
+    double e[MAXN];
+    for (int i = 0; i < nx; ++i) e[i] = st.e_buf[b * nx + i];
+    int out = 0;
+    for (int r = threadIdx.x; r < m.rZ; r += blockDim.x) {
+        double v = -m.hZ[r];
+        for (int i = 0; i < nx; ++i) v += m.HZ[r * nx + i] * e[i];
+        out |= (v > 1e-7);                                  // polytope's abs_tol
+    }
+    out = __syncthreads_or(out);
+    if (threadIdx.x == 0 && out) st.tube_viol[b] += 1;
+}
+
 }  // namespace
+
+hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStream_t stream) {
+    if (m.rZ <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mc_tube_kernel, dim3(static_cast<unsigned>(B)), dim3(128), 0, stream, m, st, B);
+    return hipGetLastError();
+}
 
 hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream) {
     const int threads = 256;
