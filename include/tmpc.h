@@ -40,6 +40,7 @@ extern "C" {
 #define TMPC_STATUS_MAX_ITER    1   /* iteration cap hit; last iterate returned          */
 #define TMPC_STATUS_INFEASIBLE  2   /* no x satisfies the constraints for this (x_k)     */
 #define TMPC_STATUS_NUMERICAL   3
+#define TMPC_STATUS_UNBOUNDED   4   /* tmpc_lp_batch only: the objective is unbounded on the set */
 
 /*
  * Problem description: everything `TubeTrackingMPC.generate_optimization_problem`
@@ -253,6 +254,34 @@ int tmpc_get_dims(const tmpc_handle *h, int variant, int32_t *nv, int32_t *nc, i
  */
 int tmpc_get_condensed(const tmpc_handle *h, int variant,
                        double *H, double *F1, double *F2, double *G, double *g0, double *E);
+
+/*
+ * Offline stage: a batch of support-function linear programs over ONE polytope,
+ *
+ *        val[b] = max  C[b,:] . x   s.t.  H x <= h   (row relax[b] of h raised by relax_by)
+ *
+ * Replaces the one-at-a-time scipy.optimize.linprog calls of the reference's set
+ * computations (reference src/LinearMPCOverNetworks/utils_polytope.py:12-23 `support`,
+ * :19 the linprog call; used by the Gilbert-Tan recursion :247-268, the Pontryagin
+ * difference :25-38, and the redundancy removal of polytope.reduce,
+ * TubeRegulatorMPC.py:74).  One wavefront per LP: interior-point iterations handed over
+ * to primal active-set steps, so that the value is the vertex value (csrc/tmpc_lp.hip).
+ *
+ *   d       dimension, 1 <= d <= 16           nr  rows of H (row-major nr x d), nr >= 1
+ *   B       number of objectives              C   B x d, row-major
+ *   relax   B row indices or NULL; relax[b] = -1 leaves h alone.  Row relax[b] is raised
+ *           by relax_by IN THE UNITS OF h AS PASSED (the redundancy test of row i is
+ *           "maximise H[i,:] x with h[i] + 1", polytope.reduce)
+ *   val     B        x   B x d maximiser or NULL
+ *   status  B  TMPC_STATUS_* (OPTIMAL: vertex-exact or converged to 1e-9; MAX_ITER: last
+ *           iterate, accurate to about 1e-8; INFEASIBLE; UNBOUNDED: val = +inf)
+ *   iters   B  interior-point iterations
+ * All pointers are HOST pointers (this is a set-up step; the data is small).  Errors:
+ * negative TMPC_E_* code, text through tmpc_last_error(NULL).
+ */
+int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const double *h,
+                  int64_t B, const double *C, const int32_t *relax, double relax_by,
+                  double *val, double *x, int32_t *status, int32_t *iters);
 
 #ifdef __cplusplus
 }

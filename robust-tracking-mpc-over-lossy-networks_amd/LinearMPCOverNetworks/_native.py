@@ -93,6 +93,9 @@ def lib():
         L.tmpc_mc_set_actuator.restype = C.c_int
         L.tmpc_mc_set_plant.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
         L.tmpc_mc_set_plant.restype = C.c_int
+        L.tmpc_lp_batch.argtypes = [C.c_int, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                    C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tmpc_lp_batch.restype = C.c_int
         L.tmpc_synchronize.argtypes = [C.c_void_p]
         L.tmpc_synchronize.restype = C.c_int
         L.tmpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -306,4 +309,33 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
         raise RuntimeError(f"tmpc_mc_run failed ({rc}): {h.error()}")
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
+    return out
+
+
+def lp_batch(H, h, Cmat, relax=None, relax_by: float = 1.0, device: int = 0, want_x: bool = False) -> dict:
+    """Batch of support-function LPs over one polytope (include/tmpc.h: tmpc_lp_batch):
+    val[b] = max Cmat[b] . x  s.t.  H x <= h, row relax[b] of h raised by relax_by."""
+    L = lib()
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    h = np.ascontiguousarray(h, dtype=np.float64).reshape(-1)
+    Cm = np.ascontiguousarray(np.atleast_2d(Cmat), dtype=np.float64)
+    nr, d = H.shape
+    if h.size != nr or Cm.shape[1] != d:
+        raise ValueError("lp_batch: shapes of H (nr x d), h (nr), C (B x d) do not agree")
+    B = Cm.shape[0]
+    rel = None if relax is None else np.ascontiguousarray(relax, dtype=np.int32).reshape(-1)
+    if rel is not None and rel.size != B:
+        raise ValueError("lp_batch: relax needs one row index per objective")
+    val = np.empty(B)
+    x = np.empty((B, d)) if want_x else None
+    st = np.empty(B, dtype=np.int32)
+    it = np.empty(B, dtype=np.int32)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = L.tmpc_lp_batch(int(device), d, nr, ptr(H), ptr(h), B, ptr(Cm), ptr(rel), float(relax_by),
+                         ptr(val), ptr(x), ptr(st), ptr(it))
+    if rc != 0:
+        raise RuntimeError(f"tmpc_lp_batch failed ({rc}): {L.tmpc_last_error(None).decode()}")
+    out = {"val": val, "status": st, "iters": it}
+    if want_x:
+        out["x"] = x
     return out

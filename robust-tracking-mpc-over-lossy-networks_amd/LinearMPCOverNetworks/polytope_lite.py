@@ -11,8 +11,18 @@ keeps the three behaviours the reference relies on:
 * `P.A`, `P.b`     -> float64 arrays, `b` flat
 * `reduce(P)`      -> LP-based removal of redundant rows (TubeRegulatorMPC.py:74)
 
-Everything here runs once per model on the host; nothing in this file is on
-the per-timestep hot path.
+Everything here runs once per model; nothing in this file is on the per-timestep
+hot path.  The linear programs behind the set operations are all support
+functions of one polytope along many directions; they go through `lp_max_batch`,
+which has two back-ends chosen with `set_lp_backend`:
+
+* "hip"   (default) one launch of the batched LP kernel per set operation
+          (include/tmpc.h: tmpc_lp_batch, csrc/tmpc_lp.hip), dimension <= 16;
+* "scipy" one `scipy.optimize.linprog(method="highs")` call per LP -- what the
+          reference does (utils_polytope.py:19); the oracle of the LP kernel in
+          the tests, and the back-end for hosts without a GPU.
+
+There is no silent switch between the two: a missing GPU or library raises.
 """
 from __future__ import annotations
 
@@ -106,8 +116,28 @@ def box_bounds(P: Polytope):
     return lo, hi
 
 
+_LP_BACKEND = "hip"
+_LP_DEVICE = 0
+LP_MAX_DIM_HIP = 16
+
+
+def set_lp_backend(name: str, device: int = 0) -> str:
+    """Choose who solves the set-up LPs: "hip" (batched kernel) or "scipy" (HiGHS, one call per LP).
+    Returns the previous choice."""
+    global _LP_BACKEND, _LP_DEVICE
+    if name not in ("hip", "scipy"):
+        raise ValueError('lp backend must be "hip" or "scipy"')
+    old = _LP_BACKEND
+    _LP_BACKEND, _LP_DEVICE = name, int(device)
+    return old
+
+
+def get_lp_backend() -> str:
+    return _LP_BACKEND
+
+
 def _lp_max(c, A, b):
-    """max c^T x s.t. A x <= b (free x). Returns (value, status)."""
+    """max c^T x s.t. A x <= b (free x) by HiGHS (utils_polytope.py:19). Returns (value, status)."""
     res = linprog(-np.asarray(c, dtype=np.float64).reshape(-1), A_ub=A, b_ub=b,
                   bounds=(None, None), method="highs")
     if res.status != 0:
@@ -115,29 +145,74 @@ def _lp_max(c, A, b):
     return -res.fun, 0
 
 
+def lp_max_batch(C, A, b, relax=None, relax_by: float = 1.0, want_x: bool = False):
+    """val[k] = max C[k] . x  s.t.  A x <= b, with row relax[k] of b raised by relax_by (relax[k] = -1: none).
+
+    Returns (val, status[, x]); status uses scipy's codes: 0 solved, 2 infeasible, 3 unbounded, 4 numerical
+    trouble.  val is +inf when unbounded and nan for the other failures."""
+    C = np.atleast_2d(np.asarray(C, dtype=np.float64))
+    A = np.asarray(A, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64).reshape(-1)
+    nb = C.shape[0]
+    rel = np.full(nb, -1, dtype=np.int32) if relax is None else np.asarray(relax, dtype=np.int32).reshape(-1)
+    if _LP_BACKEND == "hip":
+        if A.shape[1] > LP_MAX_DIM_HIP:
+            raise ValueError(f"the batched LP kernel covers dimension <= {LP_MAX_DIM_HIP}; this polytope has "
+                             f'dimension {A.shape[1]}: call set_lp_backend("scipy") for it')
+        from . import _native
+        out = _native.lp_batch(A, b, C, relax=rel, relax_by=relax_by, device=_LP_DEVICE, want_x=want_x)
+        st = np.select([out["status"] <= 1, out["status"] == 2, out["status"] == 4], [0, 2, 3], default=4).astype(int)
+        return (out["val"], st, out["x"]) if want_x else (out["val"], st)
+    val = np.empty(nb)
+    st = np.zeros(nb, dtype=int)
+    xs = np.full((nb, A.shape[1]), np.nan)
+    for k in range(nb):
+        bk = b
+        if rel[k] >= 0:
+            bk = b.copy()
+            bk[rel[k]] += relax_by
+        res = linprog(-C[k], A_ub=A, b_ub=bk, bounds=(None, None), method="highs")
+        st[k] = res.status
+        if res.status == 0:
+            val[k] = -res.fun
+            xs[k] = res.x
+        else:
+            val[k] = np.inf if res.status == 3 else np.nan
+    return (val, st, xs) if want_x else (val, st)
+
+
 def reduce(P: Polytope, abs_tol: float = ABS_TOL) -> Polytope:
     """Remove redundant rows: row i is dropped when max a_i x over the other rows
-    (with b_i relaxed by one) does not exceed b_i + abs_tol."""
+    (with b_i relaxed by one) does not exceed b_i + abs_tol.
+
+    The reference's `polytope.reduce` walks the rows one LP at a time.  Here ONE batch tests every row against
+    all the others: a row that cuts even then cuts for any subset (kept), a row that is slack by more than
+    abs_tol is never tight on the set, and all such rows can leave together without changing the set.  Only the
+    rows within abs_tol of their bound (ties, near-duplicates) are order dependent; they are walked in index
+    order like the reference does."""
     P = Polytope(P.A, P.b, normalize=True)
     A, b = P.A, P.b
-    keep = np.ones(len(b), dtype=bool)
-    for i in range(len(b)):
+    n = len(b)
+    if n <= 1:
+        return P
+    val, st = lp_max_batch(A, A, b, relax=np.arange(n), relax_by=1.0)
+    cuts = (st != 0) | (val > b + abs_tol)
+    slack = (st == 0) & (val < b - abs_tol)
+    keep = ~slack
+    for i in np.flatnonzero(~cuts & ~slack):
         keep[i] = False
         if not keep.any():
             keep[i] = True
             continue
         Ai = np.r_[A[keep], A[i:i + 1]]
         bi = np.r_[b[keep], b[i] + 1.0]
-        val, st = _lp_max(A[i], Ai, bi)
-        if st != 0 or val > b[i] + abs_tol:
+        v, s1 = lp_max_batch(A[i], Ai, bi)
+        if s1[0] != 0 or v[0] > b[i] + abs_tol:
             keep[i] = True
     return Polytope(A[keep], b[keep])
 
 
 def is_subset(P: Polytope, Q: Polytope, abs_tol: float = ABS_TOL) -> bool:
     """P subset of Q  <=>  support_P(q_i) <= b_i for every row of Q."""
-    for a, bi in zip(Q.A, Q.b):
-        val, st = _lp_max(a, P.A, P.b)
-        if st != 0 or val > bi + abs_tol:
-            return False
-    return True
+    val, st = lp_max_batch(Q.A, P.A, P.b)
+    return bool(np.all((st == 0) & (val <= Q.b + abs_tol)))

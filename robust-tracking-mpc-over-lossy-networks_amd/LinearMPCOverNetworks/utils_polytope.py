@@ -28,7 +28,7 @@ import numpy as np
 from scipy.optimize import linprog
 from scipy.spatial import ConvexHull, HalfspaceIntersection
 
-from .polytope_lite import (ABS_TOL, Polytope, _lp_max, as_polytope, box_bounds,
+from .polytope_lite import (ABS_TOL, Polytope, as_polytope, box_bounds, lp_max_batch,
                             reduce)
 
 
@@ -44,11 +44,12 @@ class LinearImage:
         return self.M.shape[0]
 
 
-def support(poly, x) -> float:
-    """h_P(x) = max_{y in P} x^T y  (utils_polytope.py:12-23)."""
-    x = np.asarray(x, dtype=np.float64).reshape(-1)
+def support_batch(poly, X) -> np.ndarray:
+    """h_P(x) = max_{y in P} x^T y for every row x of X: closed form over a box, otherwise one batch of LPs
+    (utils_polytope.py:12-23 evaluates them one linprog call at a time)."""
+    X = np.atleast_2d(np.asarray(X, dtype=np.float64))
     if isinstance(poly, LinearImage):
-        return support(poly.P, poly.M.T @ x)
+        return support_batch(poly.P, X @ poly.M)
     poly = as_polytope(poly)
     bb = getattr(poly, "_box", False)
     if bb is False:
@@ -56,21 +57,23 @@ def support(poly, x) -> float:
         poly._box = bb
     if bb is not None:
         lo, hi = bb
-        return float(np.sum(np.where(x >= 0, x * hi, x * lo)))
-    val, st = _lp_max(x, poly.A, poly.b)
-    if st != 0:
-        print(f"Status of the support linear program: {st}")
-    return float(val)
+        return np.sum(np.where(X >= 0, X * hi, X * lo), axis=1)
+    val, st = lp_max_batch(X, poly.A, poly.b)
+    for s1 in st[st != 0]:
+        print(f"Status of the support linear program: {s1}")
+    return val
+
+
+def support(poly, x) -> float:
+    """h_P(x) = max_{y in P} x^T y  (utils_polytope.py:12-23)."""
+    return float(support_batch(poly, np.asarray(x, dtype=np.float64).reshape(1, -1))[0])
 
 
 def pont_diff(poly1, poly2) -> Polytope:
     """P1 (-) P2 = {x | x + y in P1 for all y in P2}: same rows as P1, offsets
     reduced by the support of P2 along each row (utils_polytope.py:25-38)."""
     poly1 = as_polytope(poly1)
-    b = poly1.b.copy()
-    for i, a in enumerate(poly1.A):
-        b[i] -= support(poly2, a)
-    return Polytope(poly1.A.copy(), b)
+    return Polytope(poly1.A.copy(), poly1.b - support_batch(poly2, poly1.A))
 
 
 def extreme(poly) -> np.ndarray:
@@ -205,22 +208,17 @@ def calculate_maximum_admissible_output_set(A, X, abs_tol: float = ABS_TOL, t_ma
     while t < t_max:
         At = At @ A
         Gn = G @ At
-        added = False
-        newH, newh = [], []
-        for a, bi in zip(Gn, f):
-            if np.linalg.norm(a) < 1e-14:
-                continue
-            val, st = _lp_max(a, H, h)
-            if st != 0 or val > bi + abs_tol:
-                newH.append(a)
-                newh.append(bi)
-                added = True
+        live = np.linalg.norm(Gn, axis=1) >= 1e-14
+        val, st = lp_max_batch(Gn[live], H, h)         # the rows of one step are tested against the same O_t
+        cut = (st != 0) | (val > f[live] + abs_tol)
+        newH, newh = Gn[live][cut], f[live][cut]
+        added = bool(cut.any())
         if not added:
             if verbose:
                 print(f"Admissible set calculation has converged at t = {t}")
             break
-        H = np.r_[H, np.array(newH)]
-        h = np.r_[h, np.array(newh)]
+        H = np.r_[H, newH]
+        h = np.r_[h, newh]
         t += 1
     return reduce(Polytope(H, h), abs_tol)
 
@@ -254,8 +252,8 @@ def calculate_RPI(A, W, X, U, K, eps_var: float = 1e-4, s_max: int = 20,
     while k_star < s_max and not found:
         HwAk = Hw @ A_pwr[k_star]
         HdAj = Hd @ A_pwr[k_star - 1]
-        cond_a = all((1 + eps_var) * support(W, HwAk[i]) <= eps_var * hw[i] for i in range(Hw.shape[0]))
-        inc = np.array([support(W, HdAj[l]) for l in range(nd)])
+        cond_a = bool(np.all((1 + eps_var) * support_batch(W, HwAk) <= eps_var * hw))
+        inc = support_batch(W, HdAj)
         bc_all[:, k_star - 1] = inc if k_star == 1 else bc_all[:, k_star - 2] + inc
         cond_b = bool(np.all((1 + eps_var) * bc_all[:, k_star - 1] <= hd))
         if cond_a and cond_b:
@@ -270,10 +268,9 @@ def calculate_RPI(A, W, X, U, K, eps_var: float = 1e-4, s_max: int = 20,
     hc = (1 + eps_var) * bc_all[:, k_star - 1]
     C = Polytope(Hd, hc)
     HcAk = Hd @ A_pwr[k_star]
-    for i in range(nd):
-        if not (1 + eps_var) * support(C, HcAk[i]) <= eps_var * hc[i]:
-            print("The container set C does not fulfill the condition for calculating the RPI. Returning None")
-            return None, -1
+    if not np.all((1 + eps_var) * support_batch(C, HcAk) <= eps_var * hc):
+        print("The container set C does not fulfill the condition for calculating the RPI. Returning None")
+        return None, -1
     H_rows = [Hd]
     h_rows = [hc]
     for i in range(1, k_star):
@@ -298,16 +295,20 @@ def project_polytope(P, E, tol: float = 1e-9, max_vertices: int = 2000) -> Polyt
     E = np.atleast_2d(np.asarray(E, dtype=np.float64))
     k = E.shape[0]
 
+    def sup_batch(directions):
+        directions = np.atleast_2d(directions)
+        _, st, xs = lp_max_batch(directions @ E, P.A, P.b, want_x=True)
+        if np.any(st != 0):
+            raise ValueError("projection: LP failed (status %d); polytope unbounded or empty?" % st[st != 0][0])
+        return xs @ E.T
+
     def sup(direction):
-        res = linprog(-(direction @ E), A_ub=P.A, b_ub=P.b, bounds=(None, None), method="highs")
-        if res.status != 0:
-            raise ValueError("projection: LP failed (status %d); polytope unbounded or empty?" % res.status)
-        return E @ res.x
+        return sup_batch(direction)[0]
 
     if k == 1:
         hi, lo = sup(np.array([1.0]))[0], sup(np.array([-1.0]))[0]
         return Polytope([[1.0], [-1.0]], [hi, -lo], vertices=np.array([[lo], [hi]]))
-    pts = [sup(d) for d in np.r_[np.eye(k), -np.eye(k)]]
+    pts = list(sup_batch(np.r_[np.eye(k), -np.eye(k)]))
     rng = np.random.default_rng(0)
     while np.linalg.matrix_rank(np.array(pts)[1:] - pts[0], tol=1e-9) < k:
         if len(pts) > 2 * k + 50:
@@ -322,17 +323,15 @@ def project_polytope(P, E, tol: float = 1e-9, max_vertices: int = 2000) -> Polyt
         _, idx = np.unique(np.round(eq, 10), axis=0, return_index=True)
         eq = eq[np.sort(idx)]
         added = False
-        for row in eq:
-            key = tuple(np.round(row, 9))
-            if key in verified:
-                continue
+        todo = [row for row in eq if tuple(np.round(row, 9)) not in verified]
+        ys = sup_batch(np.array([row[:-1] for row in todo])) if todo else []
+        for row, y in zip(todo, ys):
             a, b = row[:-1], -row[-1]
-            y = sup(a)
             if a @ y > b + tol * max(1.0, abs(b)):
                 pts = np.vstack([pts, y])
                 added = True
             else:
-                verified.add(key)
+                verified.add(tuple(np.round(row, 9)))
         if not added:
             return Polytope(eq[:, :-1], -eq[:, -1], vertices=pts[hull.vertices])
         if len(pts) > max_vertices:

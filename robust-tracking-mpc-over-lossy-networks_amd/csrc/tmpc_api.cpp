@@ -3,6 +3,7 @@
 // (tmpc_kernels.hip) on the handle's stream.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <algorithm>
 #include <cstdint>
@@ -350,6 +351,16 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
 
 }  // namespace
 
+// device buffer of tmpc_lp_batch
+namespace {
+struct DevBuf {      // frees on scope exit (this entry point owns no handle)
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <class T> T *as() { return static_cast<T *>(p); }
+};
+}  // namespace
+
 extern "C" {
 
 int tmpc_abi_version(void) { return TMPC_ABI_VERSION; }
@@ -670,6 +681,91 @@ int tmpc_get_condensed(const tmpc_handle *h, int variant, double *H, double *F1,
     if (G) std::memcpy(G, c.G.a.data(), c.G.a.size() * sizeof(double));
     if (g0) std::memcpy(g0, c.g0.data(), c.g0.size() * sizeof(double));
     if (E) std::memcpy(E, c.E.a.data(), c.E.a.size() * sizeof(double));
+    return TMPC_OK;
+}
+
+// ---- offline stage: batched support-function LPs (tmpc_lp.hip)
+
+#define LP_TRY(expr)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            g_create_error = std::string("tmpc_lp_batch: " #expr ": ") + hipGetErrorString(e_); \
+            return TMPC_E_DEVICE;                                                          \
+        }                                                                                  \
+    } while (0)
+
+int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const double *hv, int64_t B, const double *C,
+                  const int32_t *relax, double relax_by, double *val, double *x, int32_t *status, int32_t *iters) {
+    if (!H || !hv || (B > 0 && (!C || !val || !status || !iters)) || B < 0) {
+        g_create_error = "tmpc_lp_batch: NULL argument";
+        return TMPC_E_INVALID;
+    }
+    const int DP = tmpc::lp_padded_dim(d);
+    if (d < 1 || DP < 0 || nr < 1) {
+        g_create_error = "tmpc_lp_batch: need 1 <= d <= 16 and nr >= 1";
+        return d > 16 ? TMPC_E_UNSUPPORTED : TMPC_E_INVALID;
+    }
+    if (relax)
+        for (int64_t b = 0; b < B; ++b)
+            if (relax[b] < -1 || relax[b] >= nr) { g_create_error = "tmpc_lp_batch: relax index out of range"; return TMPC_E_INVALID; }
+    if (B == 0) return TMPC_OK;
+    // rows to unit norm, h to max |h| = 1 (one scalar: x scales with it, the directions do not)
+    const int nrp = (nr + 63) / 64 * 64;
+    std::vector<double> Ht(static_cast<size_t>(DP) * nrp, 0.0), hs(nrp, 1.0), rs(nrp, 0.0);
+    double hm = 0.0;
+    for (int r = 0; r < nr; ++r) {
+        double n2 = 0.0;
+        for (int j = 0; j < d; ++j) {
+            const double v = H[static_cast<size_t>(r) * d + j];
+            if (!(v == v) || std::isinf(v)) { g_create_error = "tmpc_lp_batch: H is not finite"; return TMPC_E_INVALID; }
+            n2 += v * v;
+        }
+        if (!(hv[r] == hv[r]) || std::isinf(hv[r])) { g_create_error = "tmpc_lp_batch: h is not finite"; return TMPC_E_INVALID; }
+        const double nrm = n2 > 0.0 ? std::sqrt(n2) : 1.0;     // a zero row stays as 0 <= h_r
+        rs[r] = 1.0 / nrm;
+        for (int j = 0; j < d; ++j) Ht[static_cast<size_t>(j) * nrp + r] = H[static_cast<size_t>(r) * d + j] / nrm;
+        hs[r] = hv[r] / nrm;
+        hm = std::max(hm, std::fabs(hs[r]));
+    }
+    if (!(hm > 0.0)) hm = 1.0;
+    for (int r = 0; r < nr; ++r) { hs[r] /= hm; rs[r] /= hm; }
+
+    LP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    LP_TRY(hipGetDeviceProperties(&prop, device));
+    const int wpb = tmpc::lp_waves_per_block();
+    const int64_t want = (B + wpb - 1) / wpb;
+    const int nblocks = static_cast<int>(std::min<int64_t>(want, 2 * static_cast<int64_t>(prop.multiProcessorCount)));
+    DevBuf dHt, dh, drs, dC, drel, dws, dval, dx, dst, dit;
+    LP_TRY(dHt.alloc(Ht.size() * sizeof(double)));
+    LP_TRY(dh.alloc(hs.size() * sizeof(double)));
+    LP_TRY(drs.alloc(rs.size() * sizeof(double)));
+    LP_TRY(dC.alloc(static_cast<size_t>(B) * d * sizeof(double)));
+    LP_TRY(dws.alloc(static_cast<size_t>(nblocks) * wpb * tmpc::lp_workspace_arrays() * nrp * sizeof(double)));
+    LP_TRY(dval.alloc(static_cast<size_t>(B) * sizeof(double)));
+    LP_TRY(dst.alloc(static_cast<size_t>(B) * sizeof(int32_t)));
+    LP_TRY(dit.alloc(static_cast<size_t>(B) * sizeof(int32_t)));
+    if (x) LP_TRY(dx.alloc(static_cast<size_t>(B) * d * sizeof(double)));
+    if (relax) {
+        LP_TRY(drel.alloc(static_cast<size_t>(B) * sizeof(int32_t)));
+        LP_TRY(hipMemcpy(drel.p, relax, static_cast<size_t>(B) * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    LP_TRY(hipMemcpy(dHt.p, Ht.data(), Ht.size() * sizeof(double), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(dh.p, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(drs.p, rs.data(), rs.size() * sizeof(double), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(dC.p, C, static_cast<size_t>(B) * d * sizeof(double), hipMemcpyHostToDevice));
+    tmpc::LpDevice lp{};
+    lp.d = d; lp.nr = nr; lp.nrp = nrp; lp.max_iter = 80;
+    lp.tol = 1e-8; lp.relax_by = relax_by; lp.hm = hm;
+    lp.Ht = dHt.as<double>(); lp.h = dh.as<double>(); lp.rscale = drs.as<double>();
+    LP_TRY(tmpc::launch_lp(lp, B, nblocks, dC.as<double>(), relax ? drel.as<int32_t>() : nullptr, dws.as<double>(), dval.as<double>(),
+                           x ? dx.as<double>() : nullptr, dst.as<int32_t>(), dit.as<int32_t>(), nullptr));
+    LP_TRY(hipDeviceSynchronize());
+    LP_TRY(hipMemcpy(val, dval.p, static_cast<size_t>(B) * sizeof(double), hipMemcpyDeviceToHost));
+    LP_TRY(hipMemcpy(status, dst.p, static_cast<size_t>(B) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    LP_TRY(hipMemcpy(iters, dit.p, static_cast<size_t>(B) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (x) LP_TRY(hipMemcpy(x, dx.p, static_cast<size_t>(B) * d * sizeof(double), hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
 

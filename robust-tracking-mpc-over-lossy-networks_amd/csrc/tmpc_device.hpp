@@ -112,6 +112,21 @@ hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStr
 hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
                           const double *x_nom0, const double *xu_ss, const int32_t *status, hipStream_t stream);
 
+// LP kernel (tmpc_lp.hip): rows scaled to unit norm, h scaled by hm so that max |h| = 1
+struct LpDevice {
+    int d, nr, nrp;       // dimension, rows, row stride (multiple of 64)
+    int max_iter;
+    double tol, relax_by, hm;
+    const double *Ht;     // [DP][nrp]  H transposed, zero padded (DP = lp_padded_dim(d))
+    const double *h;      // [nrp]      padding rows: 1
+    const double *rscale; // [nrp]      1 / (|H_r| hm): caller units of h -> kernel units
+};
+int lp_padded_dim(int d);
+int lp_waves_per_block();
+int lp_workspace_arrays();
+hipError_t launch_lp(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
+                     double *xout, int32_t *status, int32_t *iters, hipStream_t stream);
+
 size_t stream_lds_bytes(int nvp, int ncp, int nx);
 bool stream_supported(int nvp, int ncp, int nx);
 hipError_t launch_stream(const DeviceQP &qp, const StreamQP &sq, int nvp, int variant_id, int64_t B, const double *x_k,

@@ -1,0 +1,509 @@
+// Batched low-dimensional linear programs for the OFFLINE stage (gfx950):
+//
+//     val_b = max c_b' x   s.t.  H x <= h  (+ relax_by on row relax_b)
+//
+// one shared polytope (H, h) with nr rows in d <= 16 dimensions, one objective per instance.  These are the support-function
+// LPs behind the set computations that produce the (H, h) blocks of the MPC problem: the reference evaluates them one at a
+// time with scipy.optimize.linprog (reference utils_polytope.py:12-23 `support`, :19 the linprog call), several thousand per
+// model -- the Gilbert-Tan recursion (utils_polytope.py:247-268), the redundancy removal behind `pc.reduce`
+// (TubeRegulatorMPC.py:74) and the Pontryagin differences (utils_polytope.py:25-38).
+//
+// One wavefront solves one LP.  Rows are strided over the 64 lanes; the per-row state (s, lam, G x, the corrector term and
+// the step) lives in a per-wave global workspace that stays in L2, H is stored transposed so that a row sweep is coalesced.
+//
+//   1. Mehrotra predictor-corrector on the normal equations M = H' diag(lam / s) H (d x d, rows of M on the lanes,
+//      LDL' by readlane elimination), infeasible start -- same iteration as the QP kernels without the Hessian.
+//   2. Hand-over at tol: the rows with lam > s are the IPM's guess of the optimal face.  A greedy pass keeps the most
+//      active ones that are linearly independent; primal active-set steps then make the answer exact: project onto the face,
+//      multipliers by least squares; a violated row replaces the working row it is (nearly) parallel to, a negative
+//      multiplier leaves, a remaining component of c along the face is followed to the blocking row.  Accept when the
+//      point is feasible, the multipliers are non-negative and c is in the cone of the working rows.
+//   3. Otherwise the IPM continues with a 100 times tighter tolerance and hands over again.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "tmpc_device.hpp"
+#include "tmpc_wave.hpp"
+
+namespace tmpc {
+
+namespace {
+
+using namespace wv;
+
+constexpr int LP_WPB = 4;        // waves (= LPs in flight) per workgroup
+constexpr int LP_ARR = 6;        // per-row workspace arrays: s, lam, Hx, w, ds, dlam
+
+template <int D> __host__ __device__ constexpr int lp_col_off(int j) { return j * D - j * (j - 1) / 2; }
+
+template <int D>
+struct LpLds {
+    static constexpr int NT = D * (D + 1) / 2;
+    static constexpr int RED = 16 * RED_STRIDE;
+    static constexpr int SUMS = NT + 2 * D + 8;
+    static constexpr int VEC = 8 * D;             // c, x, dx_aff, dx, xp, p, t, y
+    static constexpr int GW = D * D;              // working rows
+    static constexpr int IDX = 64 + D + 8;        // candidate ids, working ids (ints, stored in double slots)
+    static constexpr int TOTAL = RED + SUMS + VEC + GW + IDX;
+};
+
+template <int D>
+__global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t B, const double *__restrict__ C,
+                                                              const int32_t *__restrict__ relax, double *__restrict__ ws,
+                                                              double *__restrict__ val, double *__restrict__ xout,
+                                                              int32_t *__restrict__ status, int32_t *__restrict__ iters) {
+    using L = LpLds<D>;
+    constexpr int NT = L::NT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *red = smem + wave * L::TOTAL;
+    double *sums = red + L::RED;
+    double *cv = sums + L::SUMS;                 // objective, unit norm
+    double *xv = cv + D, *dxav = xv + D, *dxv = dxav + D, *xpv = dxv + D, *pv = xpv + D, *tv = pv + D, *yv = tv + D;
+    double *GW = cv + L::VEC;                    // [D][D] working rows
+    int *cidx = reinterpret_cast<int *>(GW + L::GW);   // [64] candidate rows
+    int *widx = cidx + 64;                       // [D] working rows
+
+    const int d = p.d, nr = p.nr, nrp = p.nrp;
+    const double *__restrict__ Ht = p.Ht;
+    const int slot = blockIdx.x * LP_WPB + wave, nslots = gridDim.x * LP_WPB;
+    double *s_ = ws + static_cast<size_t>(slot) * LP_ARR * nrp;
+    double *lam_ = s_ + nrp, *gz_ = lam_ + nrp, *w_ = gz_ + nrp, *ds_ = w_ + nrp, *dl_ = ds_ + nrp;
+
+    for (int64_t b = slot; b < B; b += nslots) {
+        // ---- objective
+        const double cl = lane < d ? C[b * d + lane] : 0.0;
+        const double cn = sqrt(wave_reduce<OpSum>(cl * cl));
+        const int rel = relax ? relax[b] : -1;
+        if (!(cn > 0.0) || !(cn < INFINITY)) {
+            if (lane == 0) { val[b] = cn == 0.0 ? 0.0 : NAN; status[b] = cn == 0.0 ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_NUMERICAL; iters[b] = 0; }
+            if (xout && lane < d) xout[b * d + lane] = 0.0;
+            continue;
+        }
+        if (lane < D) { cv[lane] = cl / cn; xv[lane] = 0.0; }
+        lds_fence();
+        auto hrow = [&](int r) { return p.h[r] + (r == rel ? p.relax_by * p.rscale[r] : 0.0); };
+        // ---- starting point: x = 0, slack floored, unit multipliers
+        double smin = INFINITY, hn = 1.0;
+        for (int r = lane; r < nr; r += WAVE) { const double hr = hrow(r); smin = fmin(smin, hr); hn = fmax(hn, fabs(hr)); }
+        smin = wave_reduce<OpMin>(smin);
+        hn = wave_reduce<OpMax>(hn);
+        {
+            const double fl = 0.1 * fmax(-smin, 1.0);
+            for (int r = lane; r < nrp; r += WAVE) {
+                const bool valid = r < nr;
+                s_[r] = valid ? fmax(hrow(r), fl) : 1.0;
+                lam_[r] = valid ? 1.0 : 0.0;
+                gz_[r] = 0.0;
+            }
+        }
+        const double ncd = static_cast<double>(nr);
+        int st = TMPC_STATUS_MAX_ITER, it = 0;
+        double try_tol = p.tol, rdn_last = 0.0;
+        double value = NAN;
+        bool from_polish = false;
+
+        for (;;) {
+            bool want_polish = false;
+            for (; it < p.max_iter; ++it) {
+                // ---- pass A: residuals, M = H' D H, H'(d.rp), H'lam
+                double acc[NT + 2 * D + 1];
+#pragma unroll
+                for (int k = 0; k < NT + 2 * D + 1; ++k) acc[k] = 0.0;
+                double rpn = 0.0, lmax = 0.0;
+                for (int r = lane; r < nrp; r += WAVE) {
+                    const bool valid = r < nr;
+                    const double sv = s_[r], lv = lam_[r];
+                    const double rp = valid ? gz_[r] + sv - hrow(r) : 0.0;
+                    const double dd = valid ? lv * fast_rcp(sv) : 0.0;
+                    double g[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) g[j] = Ht[static_cast<size_t>(j) * nrp + r];
+                    const double drp = dd * rp;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const double dg = dd * g[j];
+#pragma unroll
+                        for (int i = j; i < D; ++i) acc[lp_col_off<D>(j) + i - j] = fma(dg, g[i], acc[lp_col_off<D>(j) + i - j]);
+                        acc[NT + j] = fma(drp, g[j], acc[NT + j]);
+                        acc[NT + D + j] = fma(lv, g[j], acc[NT + D + j]);
+                    }
+                    acc[NT + 2 * D] = fma(sv, lv, acc[NT + 2 * D]);
+                    rpn = fmax(rpn, fabs(rp));
+                    lmax = fmax(lmax, lv);
+                }
+                reduce_to_lds<NT + 2 * D + 1>(acc, red, sums, lane);
+                rpn = wave_reduce<OpMax>(rpn);
+                lmax = wave_reduce<OpMax>(lmax);
+                const double gap = sums[NT + 2 * D], mu = gap / ncd;
+                double rdl = 0.0, objl = 0.0, xal = 0.0;
+                if (lane < D) {
+                    rdl = fabs(sums[NT + D + lane] - cv[lane]);
+                    objl = cv[lane] * xv[lane];
+                    xal = fabs(xv[lane]);
+                }
+                const double rdn = wave_reduce<OpMax>(rdl), obj = wave_reduce<OpSum>(objl), xn = wave_reduce<OpMax>(xal);
+                rdn_last = rdn;
+                if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
+                const double objs = fmax(fabs(obj), 1.0);
+                if (rdn <= 1e3 * try_tol && rpn <= try_tol * hn && gap <= try_tol * objs) { want_polish = true; break; }
+                if (xn > 1e9) { st = TMPC_STATUS_UNBOUNDED; break; }
+                if (lmax > 1e10) {
+                    double hl = 0.0;
+                    for (int r = lane; r < nr; r += WAVE) hl += hrow(r) * lam_[r];
+                    hl = wave_reduce<OpSum>(hl);
+                    if (hl < 0.0) { st = TMPC_STATUS_INFEASIBLE; break; }
+                }
+                // ---- factor M, predictor
+                double mrow[D], mdinv = 1.0;
+                double trc = 0.0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) trc += sums[lp_col_off<D>(j)];
+                {
+                    const int i = lane < D ? lane : 0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        const int lo = i < j ? i : j, hi = i < j ? j : i;
+                        double v = sums[lp_col_off<D>(lo) + hi - lo];
+                        if (i == j) v = (i < d) ? v + 1e-14 * trc : 1.0;
+                        mrow[j] = (lane < D) ? v : ((lane == j) ? 1.0 : 0.0);
+                    }
+                }
+                const double rhs_i = lane < D ? cv[lane] - sums[NT + lane] : 0.0;
+                double bb = rhs_i;
+                if (!rows_factor<D>(mrow, bb, mdinv, lane)) { st = TMPC_STATUS_NUMERICAL; break; }
+                {
+                    const double xl = rows_backsub_lane<D>(mrow, bb, mdinv, lane);
+                    if (lane < D) dxav[lane] = xl;
+                }
+                lds_fence();
+                // ---- pass B: affine step, corrector terms
+                double accb[2 * D + 2];
+#pragma unroll
+                for (int k = 0; k < 2 * D + 2; ++k) accb[k] = 0.0;
+                double rho_aff = 0.0;
+                for (int r = lane; r < nrp; r += WAVE) {
+                    const bool valid = r < nr;
+                    const double sv = s_[r], lv = lam_[r];
+                    double g[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) g[j] = Ht[static_cast<size_t>(j) * nrp + r];
+                    double gd = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) gd = fma(g[j], dxav[j], gd);
+                    const double rp = valid ? gz_[r] + sv - hrow(r) : 0.0;
+                    const double rs = valid ? fast_rcp(sv) : 0.0;
+                    const double dd = lv * rs;
+                    const double dsa = valid ? (-rp - gd) : 0.0;
+                    const double dla = valid ? (-lv - dd * dsa) : 0.0;
+                    const double rl = valid ? fast_rcp(lv) : 0.0;
+                    rho_aff = fmax(rho_aff, fmax(-dsa * rs, -dla * rl));
+                    const double w = dsa * dla;
+                    w_[r] = w;
+                    const double c1 = w * rs;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        accb[j] = fma(c1, g[j], accb[j]);
+                        accb[D + j] = fma(rs, g[j], accb[D + j]);
+                    }
+                    accb[2 * D] += sv * dla + lv * dsa;
+                    accb[2 * D + 1] += w;
+                }
+                reduce_to_lds<2 * D + 2>(accb, red, sums, lane);     // M's totals are in registers by now
+                rho_aff = wave_reduce<OpMax>(rho_aff);
+                const double aaff = rho_aff > 1.0 ? 1.0 / rho_aff : 1.0;
+                const double mu_aff = (gap + aaff * sums[2 * D] + aaff * aaff * sums[2 * D + 1]) / ncd;
+                double sigma = mu_aff / mu;
+                sigma = fmin(sigma * sigma * sigma, 1.0);
+                const double smu = sigma * mu;
+                {
+                    double b2 = lane < D ? rhs_i + sums[lane] - smu * sums[D + lane] : 0.0;
+                    rows_forward<D>(mrow, b2, lane);
+                    const double xl = rows_backsub_lane<D>(mrow, b2, mdinv, lane);
+                    if (lane < D) dxv[lane] = xl;
+                }
+                lds_fence();
+                // ---- pass C: final direction, step length
+                double om = (1.0 - aaff) * (1.0 - aaff);
+                om = fmin(fmax(om, 1e-4), 1e-2);
+                const double tau = 1.0 - om;
+                double rho = 0.0;
+                for (int r = lane; r < nrp; r += WAVE) {
+                    const bool valid = r < nr;
+                    const double sv = s_[r], lv = lam_[r];
+                    double gd = 0.0;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) gd = fma(Ht[static_cast<size_t>(j) * nrp + r], dxv[j], gd);
+                    const double rp = valid ? gz_[r] + sv - hrow(r) : 0.0;
+                    const double rs = valid ? fast_rcp(sv) : 0.0;
+                    const double dsk = valid ? (-rp - gd) : 0.0;
+                    const double dlk = valid ? (-lv + (smu - w_[r]) * rs - lv * rs * dsk) : 0.0;
+                    const double rl = valid ? fast_rcp(lv) : 0.0;
+                    rho = fmax(rho, fmax(-dsk * rs, -dlk * rl));
+                    ds_[r] = dsk;
+                    dl_[r] = dlk;
+                }
+                rho = wave_reduce<OpMax>(rho);
+                const double alpha = rho > tau ? tau / rho : 1.0;
+                // ---- pass D: update
+                for (int r = lane; r < nr; r += WAVE) {
+                    const double sv = s_[r], gz = gz_[r];
+                    const double rp = gz + sv - hrow(r);
+                    const double dsk = ds_[r];
+                    gz_[r] = gz + alpha * (-rp - dsk);
+                    s_[r] = sv + alpha * dsk;
+                    lam_[r] += alpha * dl_[r];
+                }
+                if (lane < D) xv[lane] += alpha * dxv[lane];
+                lds_fence();
+            }
+            if (!want_polish) break;
+
+            // ------------------------------------------------------------ hand-over: primal active-set steps
+            bool ok = false;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // (s, lam) are read across lanes from here on
+            {
+                // candidates: rows with lam > s, at most one per lane
+                int ncand = 0;
+                for (int r0 = 0; r0 < nrp; r0 += WAVE) {
+                    const int r = r0 + lane;
+                    const bool f = r < nr && lam_[r] > s_[r];
+                    const unsigned long long bal = __ballot(f);
+                    const int pos = ncand + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (f && pos < WAVE) cidx[pos] = r;
+                    ncand += __popcll(bal);
+                }
+                lds_fence();
+                int m = 0;
+                if (ncand <= WAVE) {
+                    // greedy choice: most active first (smallest slack), kept if independent of the rows kept so far
+                    const bool have = lane < ncand;
+                    const int myr = have ? cidx[lane] : 0;
+                    double R[D];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) R[j] = have ? Ht[static_cast<size_t>(j) * nrp + myr] : 0.0;
+                    const double skey = have ? s_[myr] : INFINITY;
+                    bool alive = have;
+                    for (int pick = 0; pick < d; ++pick) {
+                        double n2 = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D; ++j) n2 = fma(R[j], R[j], n2);
+                        const double key = (alive && n2 > 1e-8) ? skey : INFINITY;
+                        const double kmin = wave_reduce<OpMin>(key);
+                        if (!(kmin < INFINITY)) break;
+                        const unsigned long long bal = __ballot(key == kmin);
+                        const int pl = __ffsll(static_cast<long long>(bal)) - 1;
+                        const double rn = 1.0 / sqrt(readlane_d(n2, pl));
+                        double dot = 0.0;
+                        double q[D];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) { q[j] = readlane_d(R[j], pl) * rn; dot = fma(R[j], q[j], dot); }
+#pragma unroll
+                        for (int j = 0; j < D; ++j) R[j] = fma(-dot, q[j], R[j]);
+                        if (lane == pl) { alive = false; widx[m] = myr; }
+                        ++m;
+                    }
+                    lds_fence();
+                    if (lane < D) xpv[lane] = xv[lane];
+                    lds_fence();
+                    for (int round = 0; round < 24; ++round) {
+                        // ---- projection onto the face of the working rows, multipliers by least squares
+                        const bool inw = lane < m;
+                        const int wr = inw ? widx[lane] : 0;
+                        double gw[D];
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            gw[j] = inw ? Ht[static_cast<size_t>(j) * nrp + wr] : 0.0;
+                            if (lane < D) GW[lane * D + j] = gw[j];
+                        }
+                        const double hw = inw ? hrow(wr) : 0.0;
+                        lds_fence();
+                        double srow[D], sdinv = 1.0;
+#pragma unroll
+                        for (int c2 = 0; c2 < D; ++c2) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int j = 0; j < D; ++j) v = fma(gw[j], GW[c2 * D + j], v);
+                            srow[c2] = (inw && c2 < m) ? v : ((c2 == lane) ? 1.0 : 0.0);
+                        }
+                        double bdummy = 0.0;
+                        if (!rows_factor<D>(srow, bdummy, sdinv, lane)) break;
+                        if (lane < D) yv[lane] = 0.0;
+                        lds_fence();
+                        for (int sweep = 0; sweep < 2; ++sweep) {
+                            // xp -= GW' S^-1 (GW xp - hW)
+                            double b1 = 0.0;
+                            if (inw) {
+#pragma unroll
+                                for (int j = 0; j < D; ++j) b1 = fma(gw[j], xpv[j], b1);
+                                b1 -= hw;
+                            }
+                            rows_forward<D>(srow, b1, lane);
+                            const double tl = rows_backsub_lane<D>(srow, b1, sdinv, lane);
+                            if (lane < D) tv[lane] = inw ? tl : 0.0;
+                            lds_fence();
+                            if (lane < D) {
+                                double v = 0.0;
+                                for (int a = 0; a < m; ++a) v = fma(GW[a * D + lane], tv[a], v);
+                                xpv[lane] -= v;
+                            }
+                            lds_fence();
+                            // y += S^-1 GW (c - GW' y)
+                            if (lane < D) {
+                                double v = cv[lane];
+                                for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], yv[a], v);
+                                pv[lane] = v;
+                            }
+                            lds_fence();
+                            double b2 = 0.0;
+                            if (inw) {
+#pragma unroll
+                                for (int j = 0; j < D; ++j) b2 = fma(gw[j], pv[j], b2);
+                            }
+                            rows_forward<D>(srow, b2, lane);
+                            const double yl = rows_backsub_lane<D>(srow, b2, sdinv, lane);
+                            if (inw) yv[lane] += yl;
+                            lds_fence();
+                        }
+                        double pl_ = 0.0, ymin_l = INFINITY, yabs_l = 0.0;
+                        if (lane < D) {
+                            double v = cv[lane];
+                            for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], yv[a], v);
+                            pv[lane] = v;
+                            pl_ = fabs(v);
+                        }
+                        if (inw) { ymin_l = yv[lane]; yabs_l = fabs(yv[lane]); }
+                        lds_fence();
+                        const double pn = wave_reduce<OpMax>(pl_);
+                        const double ymin = wave_reduce<OpMin>(ymin_l), ymax = fmax(wave_reduce<OpMax>(yabs_l), 1.0);
+                        // ---- one sweep over all rows: worst violation, and the ratio test along p
+                        double vbest = 0.0, tbest = INFINITY;
+                        int vrow = -1, trow = -1;
+                        for (int r = lane; r < nr; r += WAVE) {
+                            double gx = 0.0, gp = 0.0;
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                const double g = Ht[static_cast<size_t>(j) * nrp + r];
+                                gx = fma(g, xpv[j], gx);
+                                gp = fma(g, pv[j], gp);
+                            }
+                            bool isw = false;
+                            for (int a = 0; a < m; ++a) isw = isw || (widx[a] == r);
+                            const double hr = hrow(r);
+                            const double rr = gx - hr;
+                            const double hi = fmax(fabs(hr), 1.0);
+                            if (!isw && rr > 1e-11 * hi && rr / hi > vbest) { vbest = rr / hi; vrow = r; }
+                            if (!isw && gp > 1e-13) {
+                                const double t = fmax(-rr, 0.0) / gp;
+                                if (t < tbest) { tbest = t; trow = r; }
+                            }
+                        }
+                        const double vmax = wave_reduce<OpMax>(vbest);
+                        if (vmax > 0.0) {
+                            // a violated row enters; it replaces the working row it is nearly parallel to
+                            const unsigned long long bal = __ballot(vbest == vmax);
+                            const int j = __builtin_amdgcn_readlane(vrow, __ffsll(static_cast<long long>(bal)) - 1);
+                            double dotl = 0.0;
+                            if (inw) {
+#pragma unroll
+                                for (int k = 0; k < D; ++k) dotl = fma(gw[k], Ht[static_cast<size_t>(k) * nrp + j], dotl);
+                                dotl = fabs(dotl);
+                            }
+                            const double dmax = wave_reduce<OpMax>(dotl);
+                            if (m > 0 && dmax > 0.99) {
+                                const unsigned long long b2 = __ballot(inw && dotl == dmax);
+                                const int i = __ffsll(static_cast<long long>(b2)) - 1;
+                                if (lane == 0) widx[i] = j;
+                            } else if (m < d) {
+                                if (lane == 0) widx[m] = j;
+                                ++m;
+                            } else {
+                                break;
+                            }
+                            lds_fence();
+                            continue;
+                        }
+                        if (m > 0 && ymin < -1e-10 * ymax) {
+                            // the most negative multiplier leaves
+                            const unsigned long long bal = __ballot(inw && ymin_l == ymin);
+                            const int i = __ffsll(static_cast<long long>(bal)) - 1;
+                            const int moved = (lane > i && lane < m) ? widx[lane] : 0;
+                            lds_fence();
+                            if (lane > i && lane < m) widx[lane - 1] = moved;
+                            --m;
+                            lds_fence();
+                            continue;
+                        }
+                        if (pn > 1e-11) {
+                            // c has a component along the face: follow it to the blocking row
+                            const double tmin = wave_reduce<OpMin>(tbest);
+                            if (!(tmin < INFINITY)) { st = TMPC_STATUS_UNBOUNDED; break; }
+                            if (m >= d) break;
+                            const unsigned long long bal = __ballot(tbest == tmin);
+                            const int j = __builtin_amdgcn_readlane(trow, __ffsll(static_cast<long long>(bal)) - 1);
+                            if (lane < D) xpv[lane] += tmin * pv[lane];
+                            if (lane == 0) widx[m] = j;
+                            ++m;
+                            lds_fence();
+                            continue;
+                        }
+                        ok = true;
+                        break;
+                    }
+                }
+            }
+            if (st == TMPC_STATUS_UNBOUNDED) break;
+            if (ok) { st = TMPC_STATUS_OPTIMAL; from_polish = true; break; }
+            if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
+            try_tol *= 1e-2;
+        }
+
+        // ---- outputs (scaled back: x by hm, the value by |c| hm)
+        {
+            const double *xs = from_polish ? xpv : xv;
+            double ol = lane < D ? cv[lane] * xs[lane] : 0.0;
+            ol = wave_reduce<OpSum>(ol);
+            value = cn * p.hm * ol;
+            const bool good = st == TMPC_STATUS_OPTIMAL || st == TMPC_STATUS_MAX_ITER;
+            if (lane == 0) {
+                val[b] = good ? value : (st == TMPC_STATUS_UNBOUNDED ? INFINITY : NAN);
+                status[b] = st;
+                iters[b] = it;
+            }
+            if (xout && lane < d) xout[b * d + lane] = good ? p.hm * xs[lane] : NAN;
+        }
+        lds_fence();
+    }
+}
+
+template <int D>
+hipError_t launch_lp_d(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
+                       double *xout, int32_t *status, int32_t *iters, hipStream_t stream) {
+    const size_t lds = static_cast<size_t>(LpLds<D>::TOTAL) * LP_WPB * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lp_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(lp_kernel<D>, dim3(nblocks), dim3(WAVE * LP_WPB), lds, stream, p, B, C, relax, ws, val, xout, status, iters);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int lp_padded_dim(int d) { return d <= 4 ? 4 : (d <= 8 ? 8 : (d <= 12 ? 12 : (d <= 16 ? 16 : -1))); }
+int lp_waves_per_block() { return LP_WPB; }
+int lp_workspace_arrays() { return LP_ARR; }
+
+hipError_t launch_lp(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
+                     double *xout, int32_t *status, int32_t *iters, hipStream_t stream) {
+    switch (lp_padded_dim(p.d)) {
+    case 4: return launch_lp_d<4>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+    case 8: return launch_lp_d<8>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+    case 12: return launch_lp_d<12>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+    case 16: return launch_lp_d<16>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace tmpc

@@ -1,4 +1,4 @@
-// Wave-level device helpers shared by the block kernel (tmpc_block.hip): DPP / readlane
+// Wave-level device helpers shared by the block kernel (tmpc_block.hip) and the LP kernel (tmpc_lp.hip): DPP / readlane
 // reductions over the 64 lanes of a gfx950 wavefront and a division-free reciprocal.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -41,6 +41,74 @@ __device__ __forceinline__ double wave_reduce(double v) {
     v = Op::f(v, dpp_mov_d<0x140>(v));   // row_mirror
     const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
     return Op::f(Op::f(r0, r1), Op::f(r2, r3));
+}
+
+// Orders one wave's LDS traffic for the compiler (the hardware runs the DS instructions of a wave in issue order).
+__device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
+
+// Sum each of acc[0..CNT) over the 64 lanes, totals to out[0..CNT) (LDS).  `red` is a [16][68] tile: 16 entries per round
+// are written as rows (lane l at column l + l/16), lane l then adds the 16-lane quarter (l & 3) of entry (l >> 2) and
+// the four quarters of a quad meet through two DPP quad permutes.
+constexpr int RED_STRIDE = 68;
+template <int CNT>
+__device__ __forceinline__ void reduce_to_lds(const double (&acc)[CNT], double *red, double *out, int lane) {
+    const int e = lane >> 2, qd = lane & 3;
+    const int wcol = lane + (lane >> 4);
+#pragma unroll
+    for (int c0 = 0; c0 < CNT; c0 += 16) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (c0 + k < CNT) red[k * RED_STRIDE + wcol] = acc[c0 + k];
+        lds_fence();
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t += red[e * RED_STRIDE + qd * 17 + j];
+        t += dpp_mov_d<0xB1>(t);
+        t += dpp_mov_d<0x4E>(t);
+        if (qd == 0 && c0 + e < CNT) out[c0 + e] = t;
+        lds_fence();
+    }
+}
+
+// n x n symmetric positive definite solve with the rows on the lanes: lane i (< N) holds row i in registers; LDL' by
+// Gaussian elimination without pivoting, the pivot row broadcast with v_readlane.  `b` is carried as an extra column.
+template <int N>
+__device__ __forceinline__ bool rows_factor(double (&row)[N], double &b, double &dinv, int lane) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double pkk = readlane_d(row[k], k);
+        ok = ok && (pkk > 0.0);
+        const double pinv = fast_rcp(pkk);
+        const double f = (lane > k) ? row[k] * pinv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) row[j] = fma(-f, readlane_d(row[j], k), row[j]);
+        b = fma(-f, readlane_d(b, k), b);
+        if (lane > k) row[k] = f;
+        if (lane == k) dinv = pinv;
+    }
+    return ok;
+}
+template <int N>
+__device__ __forceinline__ void rows_forward(const double (&row)[N], double &b, int lane) {
+#pragma unroll
+    for (int k = 0; k < N - 1; ++k) {
+        const double f = (lane > k) ? row[k] : 0.0;
+        b = fma(-f, readlane_d(b, k), b);
+    }
+}
+// back substitution; x_i is returned on lane i
+template <int N>
+__device__ __forceinline__ double rows_backsub_lane(const double (&row)[N], double b, double dinv, int lane) {
+    double xl = 0.0;
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        const double bi = b * dinv;
+        const double xi = readlane_d(bi, i);
+        xl = (lane == i) ? bi : xl;
+        b = fma(-row[i], xi, b);
+    }
+    return xl;
 }
 
 }  // namespace wv

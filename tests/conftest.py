@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "robust-tracking
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Set-up LPs in the tests go through scipy's HiGHS -- the solver the reference calls (utils_polytope.py:19) and the
+    # oracle of the batched LP kernel; tests/test_lp_kernel.py switches to the kernel explicitly.
+    from LinearMPCOverNetworks import polytope_lite
+    polytope_lite.set_lp_backend("scipy")
 
 
 @pytest.fixture(scope="session")

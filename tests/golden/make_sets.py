@@ -18,6 +18,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "..", "..", "robust-tracking-mpc-over-lossy-networks_amd"))
 
+from LinearMPCOverNetworks import polytope_lite  # noqa: E402
 from LinearMPCOverNetworks import utils_polytope as up  # noqa: E402
 from LinearMPCOverNetworks import workloads  # noqa: E402
 from LinearMPCOverNetworks.TubeTrackingMPC import TubeTrackingMPC  # noqa: E402
@@ -38,6 +39,7 @@ def make(name, w, rpi_method):
 
 
 if __name__ == "__main__":
+    polytope_lite.set_lp_backend("scipy")      # the fixtures come from the solver the reference calls
     make("double_integrator_rakovic", workloads.double_integrator(), 0)
     make("double_integrator_darup", workloads.double_integrator(), 1)
     make("cartpole", workloads.cartpole(), 1)

@@ -1,0 +1,174 @@
+"""Batched LP kernel of the offline stage (include/tmpc.h: tmpc_lp_batch, csrc/tmpc_lp.hip).
+
+Oracle: scipy.optimize.linprog(method="highs"), the call the reference makes for every support
+function (reference utils_polytope.py:19).  Tolerance: the kernel hands its interior-point iterate over
+to exact active-set steps, HiGHS answers to its own 1e-7 feasibility tolerance, so values agree to 1e-8
+relative (observed: 1e-10 and better), and sets built from them agree row for row.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import common
+from LinearMPCOverNetworks import polytope_lite as pl
+from LinearMPCOverNetworks import utils_polytope as up
+from LinearMPCOverNetworks.polytope_lite import Polytope
+
+RTOL = 1e-8
+
+
+def _sets(name):
+    return dict(np.load(os.path.join(common.GOLDEN, name)))
+
+
+def _reduce_one_by_one(P, abs_tol=pl.ABS_TOL):
+    """The reference's order of work: one LP per row, each against the rows still kept."""
+    P = Polytope(P.A, P.b, normalize=True)
+    A, b = P.A, P.b
+    keep = np.ones(len(b), dtype=bool)
+    for i in range(len(b)):
+        keep[i] = False
+        if not keep.any():
+            keep[i] = True
+            continue
+        val, st = pl._lp_max(A[i], np.r_[A[keep], A[i:i + 1]], np.r_[b[keep], b[i] + 1.0])
+        if st != 0 or val > b[i] + abs_tol:
+            keep[i] = True
+    return Polytope(A[keep], b[keep])
+
+
+# ------------------------------------------------------------------ CPU: host logic around the kernel
+def test_batched_reduce_equals_row_by_row_reduce():
+    """reduce() tests all rows in one batch and walks only the ties; same rows kept as the sequential walk
+    (scipy back-end on both sides) -- including exact duplicates and rows touching a vertex."""
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        d = 2 + trial % 3
+        A = rng.standard_normal((40, d))
+        b = 1.0 + rng.random(40)
+        A = np.r_[A, A[:5], np.eye(d), -np.eye(d)]                 # duplicates, a box
+        b = np.r_[b, b[:5], np.full(2 * d, 0.8)]
+        P = Polytope(A, b)
+        got, want = pl.reduce(P), _reduce_one_by_one(P)
+        assert got.A.shape == want.A.shape
+        assert np.allclose(got.A, want.A) and np.allclose(got.b, want.b)
+    s = _sets("double_integrator_darup_sets.npz")
+    P = Polytope(np.r_[s["Z_A"], s["Z_A"][::3]], np.r_[s["Z_b"], s["Z_b"][::3] + 1e-3])
+    got, want = pl.reduce(P), _reduce_one_by_one(P)
+    assert got.A.shape == want.A.shape and np.allclose(got.b, want.b)
+
+
+def test_lp_batch_rejects_bad_arguments(hip_lib):
+    """Argument checks happen before any device call (no GPU needed)."""
+    L = hip_lib.lib()
+    H = np.eye(17)
+    h = np.ones(17)
+    c = np.ones((1, 17))
+    val, st, it = np.zeros(1), np.zeros(1, np.int32), np.zeros(1, np.int32)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    assert L.tmpc_lp_batch(0, 17, 17, ptr(H), ptr(h), 1, ptr(c), None, 1.0, ptr(val), None, ptr(st), ptr(it)) == -2
+    assert b"d <= 16" in L.tmpc_last_error(None)
+    rel = np.array([5], np.int32)
+    assert L.tmpc_lp_batch(0, 2, 4, ptr(H), ptr(h), 1, ptr(c), ptr(rel), 1.0, ptr(val), None, ptr(st), ptr(it)) == -1
+    assert L.tmpc_lp_batch(0, 2, 4, None, ptr(h), 1, ptr(c), None, 1.0, ptr(val), None, ptr(st), ptr(it)) == -1
+    assert L.tmpc_lp_batch(0, 2, 4, ptr(H), ptr(h), 0, None, None, 1.0, None, None, None, None) == 0
+    with pytest.raises(ValueError):
+        old = pl.set_lp_backend("hip")
+        try:
+            pl.lp_max_batch(np.ones((1, 17)), np.eye(17), np.ones(17))
+        finally:
+            pl.set_lp_backend(old)
+
+
+# ------------------------------------------------------------------ GPU: kernel against HiGHS
+def _against_highs(A, b, Cm, rel):
+    out = pl.lp_max_batch(Cm, A, b, relax=rel, relax_by=1.0, want_x=True)
+    val, st, xs = out
+    ref = np.empty(len(Cm))
+    for i, (c, r) in enumerate(zip(Cm, rel)):
+        b2 = b.copy()
+        if r >= 0:
+            b2[r] += 1.0
+        ref[i], s1 = pl._lp_max(c, A, b2)
+        assert s1 == 0
+    assert np.all(st == 0)
+    err = np.abs(val - ref) / np.maximum(np.abs(ref), 1.0)
+    assert err.max() <= RTOL, err.max()
+    for x, r, v, c in zip(xs, rel, val, Cm):                        # the maximiser is feasible and attains the value
+        b2 = b + (np.arange(len(b)) == r) * 1.0
+        assert np.max(A @ x - b2) <= 1e-9 * max(1.0, np.abs(b2).max())
+        assert abs(c @ x - v) <= 1e-9 * max(1.0, abs(v))
+
+
+@pytest.fixture()
+def hip_lp():
+    old = pl.set_lp_backend("hip")
+    yield
+    pl.set_lp_backend(old)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,key", [("cartpole_sets.npz", "Z"), ("cartpole_sets.npz", "Xf"), ("cartpole_sets.npz", "ZmW"),
+                                      ("double_integrator_darup_sets.npz", "Z"), ("double_integrator_rakovic_sets.npz", "Xf"),
+                                      ("synthetic_sets.npz", "Z")])
+def test_support_values_match_highs(hip_lib, hip_lp, name, key):
+    """Random directions, directions along rows (degenerate: whole facets optimal) and the redundancy tests of
+    polytope.reduce (row relaxed by one), d = 2 ... 12, 26 ... 854 rows."""
+    s = _sets(name)
+    A, b = s[key + "_A"], s[key + "_b"]
+    rng = np.random.default_rng(0)
+    n = 60
+    ridx = rng.integers(0, len(b), n)
+    Cm = np.r_[rng.standard_normal((n, A.shape[1])), A[rng.integers(0, len(b), n)], A[ridx]]
+    rel = np.r_[np.full(2 * n, -1), ridx].astype(np.int32)
+    _against_highs(A, b, Cm, rel)
+
+
+@pytest.mark.gpu
+def test_lp_edge_cases(hip_lib, hip_lp):
+    box = np.r_[np.eye(3), -np.eye(3)]
+    # unbounded: the cone x <= 1 only
+    val, st = pl.lp_max_batch(np.array([[-1.0, 0, 0], [1.0, 0, 0]]), np.eye(3), np.ones(3))
+    assert st[0] == 3 and np.isinf(val[0]) and st[1] == 0 and abs(val[1] - 1.0) < 1e-12
+    # infeasible: x <= -1 and -x <= -1
+    val, st = pl.lp_max_batch(np.ones((1, 3)), np.r_[box, -np.eye(3)[:1]], np.r_[np.ones(6), -2.0])
+    assert st[0] != 0 and not np.isfinite(val[0])
+    # zero objective, single objective, tiny and huge scales, offset box (origin outside)
+    val, st = pl.lp_max_batch(np.zeros((1, 3)), box, np.ones(6))
+    assert st[0] == 0 and val[0] == 0.0
+    for scale in (1e-6, 1.0, 1e6):
+        val, st = pl.lp_max_batch(np.array([[1.0, 2.0, -3.0]]), box, scale * np.ones(6))
+        assert st[0] == 0 and abs(val[0] - 6.0 * scale) <= 1e-10 * scale
+    val, st = pl.lp_max_batch(np.array([[1.0, 1.0, 1.0]]), box, np.r_[5.0, 5.0, 5.0, -4.0, -4.0, -4.0])
+    assert st[0] == 0 and abs(val[0] - 15.0) < 1e-10
+    # many objectives, more than one pass of the persistent grid
+    rng = np.random.default_rng(1)
+    Cm = rng.standard_normal((5000, 3))
+    val, st = pl.lp_max_batch(Cm, box, np.array([1.0, 2.0, 3.0, 1.0, 2.0, 3.0]))
+    assert np.all(st == 0) and np.allclose(val, np.abs(Cm) @ np.array([1.0, 2.0, 3.0]), rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N,method", [("double_integrator", 5, 0), ("double_integrator", 10, 1), ("cartpole", 10, 1)])
+def test_offline_sets_with_the_lp_kernel_equal_the_committed_sets(hip_lib, hip_lp, name, N, method):
+    """The whole offline stage (mRPI / tightening / Gilbert-Tan terminal set / Z (-) W) driven by the LP kernel
+    reproduces the committed sets, which were computed with HiGHS: same rows, offsets to 1e-8."""
+    from LinearMPCOverNetworks.TubeTrackingMPC import TubeTrackingMPC
+    w = common.workload(name)
+    mpc = TubeTrackingMPC(w["A"], w["B"], w["Q"], w["R"], N)
+    mpc.set_input_constraints(w["U"])
+    mpc.set_state_constraints(w["X"])
+    mpc.determine_mRPI(w["W"], rpi_method=method)
+    mpc.tighten_constraints()
+    mpc.determine_Xf()
+    ZmW = up.pont_diff(mpc._Z, w["W"])
+    fix = {("double_integrator", 0): "double_integrator_rakovic_sets.npz", ("double_integrator", 1): "double_integrator_darup_sets.npz",
+           ("cartpole", 1): "cartpole_sets.npz"}[(name, method)]
+    s = _sets(fix)
+    for key, P in (("Z", mpc._Z), ("Xc", mpc._Xc), ("Uc", mpc._Uc), ("Xf", mpc._Xf), ("ZmW", ZmW)):
+        A, b = s[key + "_A"], s[key + "_b"]
+        assert P.A.shape == A.shape, (key, P.A.shape, A.shape)
+        assert np.allclose(P.A, A, rtol=0, atol=1e-9), key
+        assert np.allclose(P.b, b, rtol=0, atol=1e-8), key

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 
 import common
+from LinearMPCOverNetworks import polytope_lite as pl
 from LinearMPCOverNetworks import utils_polytope as up
 from LinearMPCOverNetworks import workloads
 from LinearMPCOverNetworks.control_lite import c2d, dlqr, dlyap
@@ -44,7 +45,7 @@ def test_support_closed_form_matches_lp():
     gen = Polytope(box.A @ np.linalg.qr(rng.normal(size=(3, 3)))[0], box.b)   # rotated: LP path
     for _ in range(10):
         a = rng.normal(size=3)
-        lp = up._lp_max(a, box.A, box.b)[0]
+        lp = pl._lp_max(a, box.A, box.b)[0]
         assert abs(up.support(box, a) - lp) < 1e-9
         assert np.isfinite(up.support(gen, a))
 
