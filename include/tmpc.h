@@ -267,7 +267,7 @@ int tmpc_get_condensed(const tmpc_handle *h, int variant,
  * TubeRegulatorMPC.py:74).  One wavefront per LP: interior-point iterations handed over
  * to primal active-set steps, so that the value is the vertex value (csrc/tmpc_lp.hip).
  *
- *   d       dimension, 1 <= d <= 16           nr  rows of H (row-major nr x d), nr >= 1
+ *   d       dimension, 1 <= d <= 32           nr  rows of H (row-major nr x d), nr >= 1
  *   B       number of objectives              C   B x d, row-major
  *   relax   B row indices or NULL; relax[b] = -1 leaves h alone.  Row relax[b] is raised
  *           by relax_by IN THE UNITS OF h AS PASSED (the redundancy test of row i is

@@ -17,7 +17,7 @@ functions of one polytope along many directions; they go through `lp_max_batch`,
 which has two back-ends chosen with `set_lp_backend`:
 
 * "hip"   (default) one launch of the batched LP kernel per set operation
-          (include/tmpc.h: tmpc_lp_batch, csrc/tmpc_lp.hip), dimension <= 16;
+          (include/tmpc.h: tmpc_lp_batch, csrc/tmpc_lp.hip), dimension <= 32;
 * "scipy" one `scipy.optimize.linprog(method="highs")` call per LP -- what the
           reference does (utils_polytope.py:19); the oracle of the LP kernel in
           the tests, and the back-end for hosts without a GPU.
@@ -118,7 +118,7 @@ def box_bounds(P: Polytope):
 
 _LP_BACKEND = "hip"
 _LP_DEVICE = 0
-LP_MAX_DIM_HIP = 16
+LP_MAX_DIM_HIP = 32
 
 
 def set_lp_backend(name: str, device: int = 0) -> str:

@@ -703,8 +703,8 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     }
     const int DP = tmpc::lp_padded_dim(d);
     if (d < 1 || DP < 0 || nr < 1) {
-        g_create_error = "tmpc_lp_batch: need 1 <= d <= 16 and nr >= 1";
-        return d > 16 ? TMPC_E_UNSUPPORTED : TMPC_E_INVALID;
+        g_create_error = "tmpc_lp_batch: need 1 <= d <= 32 and nr >= 1";
+        return d > 32 ? TMPC_E_UNSUPPORTED : TMPC_E_INVALID;
     }
     if (relax)
         for (int64_t b = 0; b < B; ++b)

@@ -2,7 +2,7 @@
 //
 //     val_b = max c_b' x   s.t.  H x <= h  (+ relax_by on row relax_b)
 //
-// one shared polytope (H, h) with nr rows in d <= 16 dimensions, one objective per instance.  These are the support-function
+// one shared polytope (H, h) with nr rows in d <= 32 dimensions, one objective per instance.  These are the support-function
 // LPs behind the set computations that produce the (H, h) blocks of the MPC problem: the reference evaluates them one at a
 // time with scipy.optimize.linprog (reference utils_polytope.py:12-23 `support`, :19 the linprog call), several thousand per
 // model -- the Gilbert-Tan recursion (utils_polytope.py:247-268), the redundancy removal behind `pc.reduce`
@@ -23,6 +23,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <utility>
 
 #include "tmpc_device.hpp"
 #include "tmpc_wave.hpp"
@@ -48,6 +49,68 @@ struct LpLds {
     static constexpr int IDX = 64 + D + 8;        // candidate ids, working ids (ints, stored in double slots)
     static constexpr int TOTAL = RED + SUMS + VEC + GW + IDX;
 };
+
+// column blocks of the lower triangle of M accumulated per row sweep (<= ~160 accumulators each)
+template <int D> struct LpBlocks { static constexpr int n = 1; static constexpr int b[2] = {0, D}; };
+template <> struct LpBlocks<32> { static constexpr int n = 5; static constexpr int b[6] = {0, 3, 7, 12, 18, 32}; };
+
+__device__ __forceinline__ double lp_hrow(const LpDevice &p, int rel, int r) {
+    return p.h[r] + (r == rel ? p.relax_by * p.rscale[r] : 0.0);
+}
+
+// Columns [J0, J1) of M = H' diag(lam / s) H over this lane's rows, summed over the wave into `sums` (packed lower
+// triangle, column-major).  The FIRST sweep also forms H'(d . r_p), H'lam, the gap, |r_p|_inf and max lam.
+template <int D, int J0, int J1, bool FIRST>
+__device__ __forceinline__ void sweep_a(const LpDevice &p, int rel, const double *s_, const double *lam_, const double *gz_, double *red,
+                                        double *sums, double &rpn, double &lmax, int lane) {
+    constexpr int NT = D * (D + 1) / 2;
+    constexpr int C0 = lp_col_off<D>(J0), CM = lp_col_off<D>(J1) - C0;
+    constexpr int CNT = CM + (FIRST ? 2 * D + 1 : 0);
+    const int nr = p.nr, nrp = p.nrp;
+    const double *__restrict__ Ht = p.Ht;
+    double acc[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) acc[k] = 0.0;
+    for (int r = lane; r < nrp; r += WAVE) {
+        const bool valid = r < nr;
+        const double sv = s_[r], lv = lam_[r];
+        const double dd = valid ? lv * fast_rcp(sv) : 0.0;
+        double g[D];
+#pragma unroll
+        for (int j = J0; j < D; ++j) g[j] = Ht[static_cast<size_t>(j) * nrp + r];
+#pragma unroll
+        for (int j = J0; j < J1; ++j) {
+            const double dg = dd * g[j];
+#pragma unroll
+            for (int i = j; i < D; ++i) acc[lp_col_off<D>(j) - C0 + i - j] = fma(dg, g[i], acc[lp_col_off<D>(j) - C0 + i - j]);
+        }
+        if constexpr (FIRST) {
+            const double rp = valid ? gz_[r] + sv - lp_hrow(p, rel, r) : 0.0;
+            const double drp = dd * rp;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                acc[CM + j] = fma(drp, g[j], acc[CM + j]);
+                acc[CM + D + j] = fma(lv, g[j], acc[CM + D + j]);
+            }
+            acc[CM + 2 * D] = fma(sv, lv, acc[CM + 2 * D]);
+            rpn = fmax(rpn, fabs(rp));
+            lmax = fmax(lmax, lv);
+        }
+    }
+    if constexpr (FIRST) {
+        static_assert(J0 == 0, "the first block starts at column 0");
+        // the block's columns, then the 2 D + 1 extra totals behind the whole triangle
+        double accm[CM], acce[2 * D + 1];
+#pragma unroll
+        for (int k = 0; k < CM; ++k) accm[k] = acc[k];
+#pragma unroll
+        for (int k = 0; k < 2 * D + 1; ++k) acce[k] = acc[CM + k];
+        reduce_to_lds<CM>(accm, red, sums, lane);
+        reduce_to_lds<2 * D + 1>(acce, red, sums + NT, lane);
+    } else {
+        reduce_to_lds<CNT>(acc, red, sums + C0, lane);
+    }
+}
 
 template <int D>
 __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t B, const double *__restrict__ C,
@@ -108,33 +171,12 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
         for (;;) {
             bool want_polish = false;
             for (; it < p.max_iter; ++it) {
-                // ---- pass A: residuals, M = H' D H, H'(d.rp), H'lam
-                double acc[NT + 2 * D + 1];
-#pragma unroll
-                for (int k = 0; k < NT + 2 * D + 1; ++k) acc[k] = 0.0;
+                // ---- pass A: residuals, M = H' D H, H'(d.rp), H'lam (for d > 16 the lower triangle of M is accumulated
+                // in column blocks, one sweep over the rows each, to stay inside the register file)
                 double rpn = 0.0, lmax = 0.0;
-                for (int r = lane; r < nrp; r += WAVE) {
-                    const bool valid = r < nr;
-                    const double sv = s_[r], lv = lam_[r];
-                    const double rp = valid ? gz_[r] + sv - hrow(r) : 0.0;
-                    const double dd = valid ? lv * fast_rcp(sv) : 0.0;
-                    double g[D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) g[j] = Ht[static_cast<size_t>(j) * nrp + r];
-                    const double drp = dd * rp;
-#pragma unroll
-                    for (int j = 0; j < D; ++j) {
-                        const double dg = dd * g[j];
-#pragma unroll
-                        for (int i = j; i < D; ++i) acc[lp_col_off<D>(j) + i - j] = fma(dg, g[i], acc[lp_col_off<D>(j) + i - j]);
-                        acc[NT + j] = fma(drp, g[j], acc[NT + j]);
-                        acc[NT + D + j] = fma(lv, g[j], acc[NT + D + j]);
-                    }
-                    acc[NT + 2 * D] = fma(sv, lv, acc[NT + 2 * D]);
-                    rpn = fmax(rpn, fabs(rp));
-                    lmax = fmax(lmax, lv);
-                }
-                reduce_to_lds<NT + 2 * D + 1>(acc, red, sums, lane);
+                [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
+                    (sweep_a<D, LpBlocks<D>::b[Ks], LpBlocks<D>::b[Ks + 1], Ks == 0>(p, rel, s_, lam_, gz_, red, sums, rpn, lmax, lane), ...);
+                }(std::make_integer_sequence<int, LpBlocks<D>::n>{});
                 rpn = wave_reduce<OpMax>(rpn);
                 lmax = wave_reduce<OpMax>(lmax);
                 const double gap = sums[NT + 2 * D], mu = gap / ncd;
@@ -156,24 +198,30 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                     hl = wave_reduce<OpSum>(hl);
                     if (hl < 0.0) { st = TMPC_STATUS_INFEASIBLE; break; }
                 }
-                // ---- factor M, predictor
+                // ---- factor M, predictor.  No regularisation unless a pivot fails: near the solution the weak directions
+                // of M carry the dual residual, a shift large enough to matter for the pivots would freeze them
                 double mrow[D], mdinv = 1.0;
                 double trc = 0.0;
 #pragma unroll
                 for (int j = 0; j < D; ++j) trc += sums[lp_col_off<D>(j)];
-                {
+                const double rhs_i = lane < D ? cv[lane] - sums[NT + lane] : 0.0;
+                double bb = rhs_i;
+                bool spd = false;
+                for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
+                    const double shift = attempt == 0 ? 0.0 : 1e-14 * trc;
                     const int i = lane < D ? lane : 0;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
                         const int lo = i < j ? i : j, hi = i < j ? j : i;
                         double v = sums[lp_col_off<D>(lo) + hi - lo];
-                        if (i == j) v = (i < d) ? v + 1e-14 * trc : 1.0;
-                        mrow[j] = (lane < D) ? v : ((lane == j) ? 1.0 : 0.0);
+                        if (i == j) v = (i < d) ? v + shift : 1.0;
+                        mrow[j] = (lane < D) ? v : 0.0;
                     }
+                    bb = rhs_i;
+                    mdinv = 1.0;
+                    spd = rows_factor<D>(mrow, bb, mdinv, lane);
                 }
-                const double rhs_i = lane < D ? cv[lane] - sums[NT + lane] : 0.0;
-                double bb = rhs_i;
-                if (!rows_factor<D>(mrow, bb, mdinv, lane)) { st = TMPC_STATUS_NUMERICAL; break; }
+                if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
                 {
                     const double xl = rows_backsub_lane<D>(mrow, bb, mdinv, lane);
                     if (lane < D) dxav[lane] = xl;
@@ -308,7 +356,7 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                     lds_fence();
                     if (lane < D) xpv[lane] = xv[lane];
                     lds_fence();
-                    for (int round = 0; round < 24; ++round) {
+                    for (int round = 0; round < 3 * d + 16; ++round) {
                         // ---- projection onto the face of the working rows, multipliers by least squares
                         const bool inw = lane < m;
                         const int wr = inw ? widx[lane] : 0;
@@ -491,7 +539,7 @@ hipError_t launch_lp_d(const LpDevice &p, int64_t B, int nblocks, const double *
 
 }  // namespace
 
-int lp_padded_dim(int d) { return d <= 4 ? 4 : (d <= 8 ? 8 : (d <= 12 ? 12 : (d <= 16 ? 16 : -1))); }
+int lp_padded_dim(int d) { return d <= 4 ? 4 : (d <= 8 ? 8 : (d <= 12 ? 12 : (d <= 16 ? 16 : (d <= 32 ? 32 : -1)))); }
 int lp_waves_per_block() { return LP_WPB; }
 int lp_workspace_arrays() { return LP_ARR; }
 
@@ -502,6 +550,7 @@ hipError_t launch_lp(const LpDevice &p, int64_t B, int nblocks, const double *C,
     case 8: return launch_lp_d<8>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
     case 12: return launch_lp_d<12>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
     case 16: return launch_lp_d<16>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+    case 32: return launch_lp_d<32>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
     default: return hipErrorInvalidValue;
     }
 }
