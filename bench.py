@@ -212,6 +212,17 @@ def main():
             out["closed_loop"] = {"value": B * Tcl / tcl, "unit": "MPC steps/s", "trajectories": B, "steps": Tcl, "p_loss": 0.3,
                                   "tube_violations": int(cl["tube_violations"].sum()), "non_optimal_solves": int(cl["not_optimal"].sum()),
                                   "note": "end to end incl. upload of the realisations and download of the statistics"}
+            # offline stage extra: support-function LPs over this workload's terminal set in one launch (tmpc_lp_batch)
+            from LinearMPCOverNetworks import _native as nat
+            Xf = mpc._Xf
+            dirs = np.random.default_rng(7).standard_normal((65536, Xf.A.shape[1]))
+            nat.lp_batch(Xf.A, Xf.b, dirs[:256])
+            tlp = time.perf_counter()
+            lp = nat.lp_batch(Xf.A, Xf.b, dirs)
+            tlp = time.perf_counter() - tlp
+            out["offline_lp"] = {"value": len(dirs) / tlp, "unit": "LP/s", "rows": int(Xf.A.shape[0]), "dim": int(Xf.A.shape[1]),
+                                 "batch": len(dirs), "solved": int((lp["status"] == 0).sum()),
+                                 "note": "support LPs over the terminal set, host buffers in and out (set-up stage, DESIGN.md 7a)"}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
