@@ -713,7 +713,8 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     // rows to unit norm, h to max |h| = 1 (one scalar: x scales with it, the directions do not)
     const int nrp = (nr + 63) / 64 * 64;
     std::vector<double> Ht(static_cast<size_t>(DP) * nrp, 0.0), hs(nrp, 1.0), rs(nrp, 0.0);
-    double hm = 0.0;
+    double hm = 0.0, nmax = 0.0;
+    std::vector<double> nrm(nr, 0.0);
     for (int r = 0; r < nr; ++r) {
         double n2 = 0.0;
         for (int j = 0; j < d; ++j) {
@@ -722,14 +723,37 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
             n2 += v * v;
         }
         if (!(hv[r] == hv[r]) || std::isinf(hv[r])) { g_create_error = "tmpc_lp_batch: h is not finite"; return TMPC_E_INVALID; }
-        const double nrm = n2 > 0.0 ? std::sqrt(n2) : 1.0;     // a zero row stays as 0 <= h_r
-        rs[r] = 1.0 / nrm;
-        for (int j = 0; j < d; ++j) Ht[static_cast<size_t>(j) * nrp + r] = H[static_cast<size_t>(r) * d + j] / nrm;
-        hs[r] = hv[r] / nrm;
+        nrm[r] = std::sqrt(n2);
+        nmax = std::max(nmax, nrm[r]);
+    }
+    // A row whose normal vanishes against the others (round-off left by a product of matrices) says 0 <= h_r: it
+    // constrains nothing, or everything.  Scaling it to unit norm would turn the round-off into a constraint.
+    bool empty_set = false;
+    for (int r = 0; r < nr; ++r) {
+        if (nrm[r] <= 1e-12 * nmax) {
+            if (hv[r] < -1e-9 * (1.0 + std::fabs(hv[r]))) empty_set = true;
+            continue;                                    // stays as the padding row 0 . x <= 1
+        }
+        rs[r] = 1.0 / nrm[r];
+        for (int j = 0; j < d; ++j) Ht[static_cast<size_t>(j) * nrp + r] = H[static_cast<size_t>(r) * d + j] / nrm[r];
+        hs[r] = hv[r] / nrm[r];
         hm = std::max(hm, std::fabs(hs[r]));
     }
+    if (empty_set || !(nmax > 0.0)) {
+        // 0 <= h_r < 0 for some r: no point satisfies the rows; no normal at all: every direction is unbounded
+        for (int64_t b = 0; b < B; ++b) {
+            val[b] = empty_set ? std::nan("") : INFINITY;
+            status[b] = empty_set ? TMPC_STATUS_INFEASIBLE : TMPC_STATUS_UNBOUNDED;
+            iters[b] = 0;
+            if (x) for (int j = 0; j < d; ++j) x[b * d + j] = std::nan("");
+        }
+        return TMPC_OK;
+    }
     if (!(hm > 0.0)) hm = 1.0;
-    for (int r = 0; r < nr; ++r) { hs[r] /= hm; rs[r] /= hm; }
+    for (int r = 0; r < nr; ++r) {
+        if (rs[r] == 0.0) continue;                      // vanishing normal: keeps h = 1 in kernel units
+        hs[r] /= hm; rs[r] /= hm;
+    }
 
     LP_TRY(hipSetDevice(device));
     hipDeviceProp_t prop;

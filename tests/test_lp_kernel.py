@@ -74,6 +74,14 @@ def test_lp_batch_rejects_bad_arguments(hip_lib):
     assert L.tmpc_lp_batch(0, 2, 4, ptr(H), ptr(h), 1, ptr(c), ptr(rel), 1.0, ptr(val), None, ptr(st), ptr(it)) == -1
     assert L.tmpc_lp_batch(0, 2, 4, None, ptr(h), 1, ptr(c), None, 1.0, ptr(val), None, ptr(st), ptr(it)) == -1
     assert L.tmpc_lp_batch(0, 2, 4, ptr(H), ptr(h), 0, None, None, 1.0, None, None, None, None) == 0
+    # rows without a normal say 0 <= h_r: decided on the host -- the set is empty (h_r < 0) or, with no normal at all, the
+    # whole space
+    Hz = np.zeros((2, 2))
+    c2 = np.ones((1, 2))
+    assert L.tmpc_lp_batch(0, 2, 2, ptr(Hz), ptr(np.array([1.0, -1.0])), 1, ptr(c2), None, 1.0, ptr(val), None, ptr(st), ptr(it)) == 0
+    assert st[0] == 2 and np.isnan(val[0])
+    assert L.tmpc_lp_batch(0, 2, 2, ptr(Hz), ptr(np.array([1.0, 1.0])), 1, ptr(c2), None, 1.0, ptr(val), None, ptr(st), ptr(it)) == 0
+    assert st[0] == 4 and np.isinf(val[0])
     with pytest.raises(ValueError):
         old = pl.set_lp_backend("hip")
         try:
@@ -149,6 +157,9 @@ def test_lp_edge_cases(hip_lib, hip_lp):
         assert st[0] == 0 and abs(val[0] - 6.0 * scale) <= 1e-10 * scale
     val, st = pl.lp_max_batch(np.array([[1.0, 1.0, 1.0]]), box, np.r_[5.0, 5.0, 5.0, -4.0, -4.0, -4.0])
     assert st[0] == 0 and abs(val[0] - 15.0) < 1e-10
+    # a row whose normal is round-off (1e-18) constrains nothing and must not be scaled into a constraint
+    val, st = pl.lp_max_batch(np.array([[1.0, 2.0, -3.0]]), np.r_[box, [[1e-18, -2e-18, 0.0]]], np.r_[np.ones(6), 0.5])
+    assert st[0] == 0 and abs(val[0] - 6.0) <= 1e-10
     # many objectives, more than one pass of the persistent grid
     rng = np.random.default_rng(1)
     Cm = rng.standard_normal((5000, 3))
@@ -192,3 +203,26 @@ def test_offline_sets_with_the_lp_kernel_equal_the_committed_sets(hip_lib, hip_l
             pl.set_lp_backend(old)
         assert np.all(s1 == 0) and np.all(s2 == 0)
         assert np.max(v1 - b) <= 1e-6 and np.max(v2 - P.b) <= 1e-6, key
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["double_integrator_darup_sets.npz", "cartpole_sets.npz"])
+def test_projection_with_the_lp_kernel(hip_lib, name):
+    """eliminate_terminal_auxiliaries (convex-hull projection, one LP batch per refinement round) gives the same
+    polytope with the LP kernel as with HiGHS."""
+    s = _sets(name)
+    w = common.workload("cartpole" if "cartpole" in name else "double_integrator")
+    Xf = Polytope(s["Xf_A"], s["Xf_b"])
+    got = {}
+    for be in ("scipy", "hip"):
+        old = pl.set_lp_backend(be)
+        try:
+            got[be] = up.eliminate_terminal_auxiliaries(Xf, w["A"], w["B"])
+        finally:
+            pl.set_lp_backend(old)
+    a, b = got["hip"], got["scipy"]
+    assert a.A.shape == b.A.shape
+    # facets may come out in a different order: compare as sets of rows
+    ka = np.lexsort(np.round(np.c_[a.A, a.b], 7).T)
+    kb = np.lexsort(np.round(np.c_[b.A, b.b], 7).T)
+    assert np.allclose(a.A[ka], b.A[kb], atol=1e-7) and np.allclose(a.b[ka], b.b[kb], atol=1e-7)
