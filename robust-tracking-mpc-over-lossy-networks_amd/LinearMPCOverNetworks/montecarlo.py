@@ -67,6 +67,26 @@ def draw_realisations(n_traj: int, T: int, w_bound, seed: int = 20240301, first:
     return th, ga, w
 
 
+def draw_realisations_reference_order(p_loss, n_mc: int, T: int, w_bound, seeds=(679, 347, 124)):
+    """The realisations of the reference's own experiment: three shared generators -- disturbance 679, gamma 347,
+    theta 124 (results_linear_system.py:21-23) -- consumed in loop order over (loss rate i, run l_mc, step t): one theta
+    and one gamma uniform per step t >= 1 (:218-226, the first transmission always succeeds, :211-214) and nx disturbance
+    components per step (:229-233).  Only valid for the whole sweep on one rank (the order is the point).
+
+    Returns (p (B,), th (B,T), ga (B,T), w (B,T,nx)), B = len(p_loss) * n_mc in (i, l_mc) order; the t = 0 entries
+    of th/ga are 1.0 (never below a loss probability)."""
+    p_loss = np.asarray(p_loss, dtype=np.float64)
+    w_bound = np.asarray(w_bound, dtype=np.float64)
+    rng_w, rng_gamma, rng_theta = (np.random.default_rng(sd) for sd in seeds)
+    nb = len(p_loss) * int(n_mc)
+    th = np.ones((nb, T))
+    ga = np.ones((nb, T))
+    th[:, 1:] = rng_theta.uniform(size=(nb, T - 1))
+    ga[:, 1:] = rng_gamma.uniform(size=(nb, T - 1))
+    w = rng_w.uniform(-w_bound, w_bound, size=(nb, T, w_bound.size))
+    return np.repeat(p_loss, int(n_mc)), th, ga, w
+
+
 def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False,
                         plant=None):
     """Closed loop of the remote tube-based MPC over a lossy network for a batch of trajectories:

@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--ref", type=float, default=0.5)          # :160
     ap.add_argument("--extended", action="store_true")
     ap.add_argument("--host-loop", action="store_true", help="state machines in numpy on the host instead of on the device")
+    ap.add_argument("--reference-streams", action="store_true",
+                    help="replay the reference's own random streams (seeds 679/347/124 consumed in its loop order, "
+                         "results_linear_system.py:21-23); single GPU only")
     args = ap.parse_args()
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
     import torch
@@ -38,8 +41,16 @@ def main():
     mpc, model = common.make_mpc("cartpole", args.N, True, extended=args.extended, create=True, device=local)
     p_loss = np.arange(10) / 10.0                              # :149
     t0 = time.time()
-    table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
-                                    extended=args.extended, device=device, on_device=not args.host_loop)
+    if args.reference_streams:
+        if world != 1:
+            raise SystemExit("--reference-streams keeps the reference's draw order and cannot be sharded")
+        pl, th, ga, wd = montecarlo.draw_realisations_reference_order(p_loss, args.n_mc, args.T, model["w_bound"])
+        out = mpc.run_closed_loop(pl, np.full(args.T, args.ref), th, ga, wd, extended=args.extended)
+        table = np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]]
+        pi = np.repeat(np.arange(len(p_loss)), args.n_mc)
+    else:
+        table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
+                                        extended=args.extended, device=device, on_device=not args.host_loop)
     dt = time.time() - t0
     if rank == 0:
         n = len(pi)

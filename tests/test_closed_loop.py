@@ -141,3 +141,26 @@ def test_device_loop_with_nonlinear_plant_equals_host_loop(hip_lib):
     # the nonlinear plant really is a different plant, and the loop still tracks the reference
     assert np.max(np.abs(dev["x_final"] - lin["x_final"])) > 1e-6
     assert np.all(dev["x_final"][:, 0] > 0.2) and np.max(np.abs(dev["x_final"][:, 2])) < 0.05     # 2 s in: on its way, pole upright
+
+
+def test_reference_stream_order():
+    """draw_realisations_reference_order consumes the three generators exactly like the reference's loops
+    (results_linear_system.py:21-23, 209-233): scalar draws in (i, l_mc, t) order."""
+    from LinearMPCOverNetworks import montecarlo
+    p_list, n_mc, T = [0.0, 0.3, 0.6], 2, 5
+    wb = np.array([0.1, 0.2, 0.3, 0.4])
+    p, th, ga, w = montecarlo.draw_realisations_reference_order(p_list, n_mc, T, wb)
+    rng_w, rng_gamma, rng_theta = np.random.default_rng(679), np.random.default_rng(347), np.random.default_rng(124)
+    k = 0
+    for i in range(len(p_list)):
+        for l_mc in range(n_mc):
+            assert p[k] == p_list[i]
+            for t in range(T):
+                if t == 0:
+                    assert th[k, 0] == 1.0 and ga[k, 0] == 1.0
+                else:
+                    assert th[k, t] == rng_theta.uniform() and ga[k, t] == rng_gamma.uniform()
+                wt = np.r_[rng_w.uniform(-wb[0], wb[0]), rng_w.uniform(-wb[1], wb[1]),
+                           rng_w.uniform(-wb[2], wb[2]), rng_w.uniform(-wb[3], wb[3])]
+                assert np.array_equal(w[k, t], wt)
+            k += 1
