@@ -226,3 +226,31 @@ def test_projection_with_the_lp_kernel(hip_lib, name):
     ka = np.lexsort(np.round(np.c_[a.A, a.b], 7).T)
     kb = np.lexsort(np.round(np.c_[b.A, b.b], 7).T)
     assert np.allclose(a.A[ka], b.A[kb], atol=1e-7) and np.allclose(a.b[ka], b.b[kb], atol=1e-7)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,nr", [(1, 2), (1, 7), (2, 3), (3, 40), (5, 64), (5, 65), (9, 300), (13, 200), (16, 128), (17, 90), (24, 400), (32, 150),
+                                  (4, 4000)])
+def test_random_polytopes_all_dimensions(hip_lib, hip_lp, d, nr):
+    """Random bounded polytopes (a box plus random cuts, shifted so that the origin is OUTSIDE, with duplicated rows)
+    in every padded dimension class of the kernel (4, 8, 12, 16, 32) and at the row-count edges (one lane pass,
+    one row over, thousands of rows)."""
+    rng = np.random.default_rng(100 * d + nr)
+    nbox = min(2 * d, nr)
+    A = np.r_[np.eye(d), -np.eye(d)][:nbox]
+    b = np.full(nbox, 2.0)
+    if nr > nbox:
+        G = rng.standard_normal((nr - nbox, d))
+        A = np.r_[A, G]
+        b = np.r_[b, 0.5 + rng.random(nr - nbox) * np.linalg.norm(G, axis=1)]
+    if nr >= 2 * d + 4:
+        A[-2:] = A[2 * d:2 * d + 2]                    # exact duplicates
+        b[-2:] = b[2 * d:2 * d + 2]
+    shift = 3.0 * rng.standard_normal(d)               # origin outside the set
+    b = b + A @ shift
+    if nr < 2 * d:                                     # not enough rows for a bounded set: only directions it bounds
+        Cm = A[rng.integers(0, nr, 20)]
+    else:
+        Cm = np.r_[rng.standard_normal((40, d)), A[rng.integers(0, nr, 20)]]
+    rel = np.full(len(Cm), -1, dtype=np.int32)
+    _against_highs(A, b, Cm, rel, hip_lib)
