@@ -78,6 +78,12 @@ class TubeRegulatorMPC(RegulatorMPC):
                     Acl, W=W, eps_var=eps_var, s_max=s_max)
             if status == 0:
                 break
+            if status == -2:
+                raise ValueError("determine_mRPI: the disturbance set is too large for the state/input constraints "
+                                 "(no RPI set fits inside them); the reference would retry with a larger s_max forever")
+            if status == -3:
+                raise ValueError("determine_mRPI: the container set of the Darup-Teichrib construction fails its contraction "
+                                 "test for this model (independent of s_max); try rpi_method=0")
             print(f"RPI not determined in {s_max} steps. Increasing s_max to 10*s_max = {10 * s_max}")
             s_max *= 10
         self._Z = reduce(Fs_temp)

@@ -256,6 +256,11 @@ def calculate_RPI(A, W, X, U, K, eps_var: float = 1e-4, s_max: int = 20,
         inc = support_batch(W, HdAj)
         bc_all[:, k_star - 1] = inc if k_star == 1 else bc_all[:, k_star - 2] + inc
         cond_b = bool(np.all((1 + eps_var) * bc_all[:, k_star - 1] <= hd))
+        if not cond_b:
+            # the partial sums only grow with k (0 is in W): once (9b) fails it fails for every larger k and every larger
+            # s_max.  The reference keeps multiplying s_max by ten here and never returns (TubeRegulatorMPC.py:48-71).
+            print("The disturbance set is too large for the constraints: no RPI set fits inside them (status -2).")
+            return None, -2
         if cond_a and cond_b:
             found, status = True, 0
         else:
@@ -269,8 +274,10 @@ def calculate_RPI(A, W, X, U, K, eps_var: float = 1e-4, s_max: int = 20,
     C = Polytope(Hd, hc)
     HcAk = Hd @ A_pwr[k_star]
     if not np.all((1 + eps_var) * support_batch(C, HcAk) <= eps_var * hc):
+        # does not depend on s_max: status -3 lets the caller stop instead of retrying with a larger s_max for ever
+        # (the reference returns -1 here and its retry loop never ends, TubeRegulatorMPC.py:48-71)
         print("The container set C does not fulfill the condition for calculating the RPI. Returning None")
-        return None, -1
+        return None, -3
     H_rows = [Hd]
     h_rows = [hc]
     for i in range(1, k_star):

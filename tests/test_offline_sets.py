@@ -164,3 +164,16 @@ def test_terminal_auxiliaries_elimination_is_exact():
         res = linprog(np.zeros(5), A_ub=np.c_[HT[:, :4], HT[:, 8:]], b_ub=hT - HT[:, 4:8] @ xu[:4], bounds=(None, None), method="highs")
         assert (res.status == 0) == inside
         assert bool(np.all(PT.A @ xu <= PT.b + 1e-12)) == inside
+
+
+def test_rpi_that_cannot_fit_is_refused():
+    """Disturbance too large for the constraints: condition (9b) of the Darup-Teichrib construction fails for every k.
+    The reference retries with s_max x 10 forever (TubeRegulatorMPC.py:48-71); here set-up stops with an error."""
+    from LinearMPCOverNetworks.TubeTrackingMPC import TubeTrackingMPC
+    A = np.array([[1.0, 1.0], [0.0, 1.0]])
+    B = np.array([[0.5], [1.0]])
+    mpc = TubeTrackingMPC(A, B, np.eye(2), np.eye(1), 5)
+    mpc.set_input_constraints(box2poly([[-0.1, 0.1]]))
+    mpc.set_state_constraints(box2poly([[-1.0, 1.0]] * 2))
+    with pytest.raises(ValueError):
+        mpc.determine_mRPI(box2poly([[-0.5, 0.5]] * 2), rpi_method=1)
