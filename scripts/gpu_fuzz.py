@@ -16,7 +16,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 worst = 0.0
 for case in range(ncase):
-    n = int(rng.integers(2, 7)); m = int(rng.integers(1, 3)); N = int(rng.integers(3, 16))
+    n = int(rng.integers(2, 9)); m = int(rng.integers(1, 3)); N = int(rng.integers(3, 27 if m == 1 else 16))
     fixed = bool(rng.integers(0, 2)); ext = bool(rng.integers(0, 2)) and n <= 4
     A0 = rng.standard_normal((n, n)); A = rng.uniform(0.7, 1.05) * A0 / np.max(np.abs(np.linalg.eigvals(A0)))
     Bm = rng.standard_normal((n, m))

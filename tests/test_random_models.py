@@ -1,0 +1,60 @@
+"""End to end on models that no named workload covers: random stable (A, B), random weights and boxes ->
+offline stage with the batched LP kernel -> device QP -> a batch of states against the CPU oracle.
+(scripts/gpu_fuzz.py runs the same loop for hundreds of models.)"""
+import contextlib
+import io
+
+import numpy as np
+import pytest
+
+from oracle.oracle import Oracle
+from LinearMPCOverNetworks import polytope_lite as pl
+from LinearMPCOverNetworks.polytope_lite import box2poly
+from LinearMPCOverNetworks.TubeTrackingMPC import ExtendedTubeTrackingMPC, TubeTrackingMPC
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_random_models_end_to_end(hip_lib, oracle_lib, seed):
+    rng = np.random.default_rng(seed)
+    old = pl.set_lp_backend("hip")
+    done, paths = 0, set()
+    try:
+        for case in range(6):
+            n, m = int(rng.integers(2, 7)), int(rng.integers(1, 3))
+            N = int(rng.integers(3, 22 if m == 1 else 14))
+            fixed = bool(rng.integers(0, 2))
+            ext = bool(rng.integers(0, 2)) and n <= 4
+            A0 = rng.standard_normal((n, n))
+            A = rng.uniform(0.7, 1.02) * A0 / np.max(np.abs(np.linalg.eigvals(A0)))
+            Bm = rng.standard_normal((n, m))
+            Q, R = np.diag(rng.uniform(0.5, 5.0, n)), np.diag(rng.uniform(0.05, 1.0, m))
+            xb, ub, wb = rng.uniform(3.0, 10.0, n), rng.uniform(0.5, 2.0, m), rng.uniform(0.002, 0.02, n)
+            mpc = (ExtendedTubeTrackingMPC if ext else TubeTrackingMPC)(A, Bm, Q, R, N)
+            mpc.set_input_constraints(box2poly(np.c_[-ub, ub]))
+            mpc.set_state_constraints(box2poly(np.c_[-xb, xb]))
+            try:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    mpc.setup_optimization(box2poly(np.c_[-wb, wb]), fixed_initial_state=fixed, rpi_method=1)
+            except ValueError:
+                continue                      # the tube does not fit this random model: a legitimate refusal
+            X = rng.uniform(-0.6, 0.6, (64, n)) * mpc._Xc.b[:n]
+            X[:16] *= 1.5
+            Rf = np.zeros((64, n))
+            Rf[:, 0] = rng.uniform(-0.5, 0.5, 64) * xb[0]
+            var = rng.integers(0, 2, 64).astype(np.uint8) if ext else None
+            orc = Oracle(mpc._problem_dict())
+            ref = orc.solve(X, Rf, var) if ext else orc.solve(X, Rf)
+            out = mpc._solve(X, Rf, var)
+            # the oracle's refinement is the weaker of the two: where it stops at "inaccurate" the kernel may be optimal
+            agree = (out["status"] == ref["status"]) | ((ref["status"] == 1) & (out["status"] == 0))
+            assert agree.all(), (seed, case, out["status"], ref["status"])
+            ok = (ref["status"] == 0) & (out["status"] == 0)
+            if ok.any():
+                np.testing.assert_allclose(out["u_nom"][ok], ref["u_nom"][ok], atol=1e-8, rtol=0)
+                np.testing.assert_allclose(out["xu_ss"][ok], ref["xu_ss"][ok], atol=1e-8, rtol=0)
+            paths.add(mpc.get_kernel_path())
+            done += 1
+    finally:
+        pl.set_lp_backend(old)
+    assert done >= 3
