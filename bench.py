@@ -199,6 +199,22 @@ def main():
             out["cpu_baseline"] = {"value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
                                    "sample": f"{ns} instances of the same workload, oracle/tmpc_oracle.c (IPM + refinement), "
                                              f"OpenMP over the batch, {tc:.2f} s wall, mean iters {oc['iters'].mean():.2f}"}
+            # the reference's Monte-Carlo loop body (results_linear_system.py:209-291) on the host cores: numpy state
+            # machines around the same CPU solver, all trajectories of a time step solved together
+            def cpu_packets(x_hat, r, gamma=None):
+                sol = orc.solve(x_hat, r, gamma, nthreads=cores)
+                u_ss = sol["u_ss"] + sol["x_ss"] @ mpc._K.T
+                U = np.concatenate([sol["u_nom"], u_ss[:, None, :]], axis=1).transpose(0, 2, 1)
+                return np.ascontiguousarray(U), sol["x_nom0"], sol["status"]
+            nbc, Tc = 2048, 50
+            thc, gac, wdc = montecarlo.draw_realisations(nbc, Tc, w["w_bound"], seed=99)
+            tcl = time.perf_counter()
+            montecarlo.run_remote_tube_mpc(cpu_packets, w["A"], w["B"], mpc.get_steady_state_controller_gain(),
+                                           mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, np.full(nbc, 0.3),
+                                           0.5 * np.ones(Tc), thc, gac, wdc)
+            tcl = time.perf_counter() - tcl
+            out["cpu_baseline"]["closed_loop"] = {"value": nbc * Tc / tcl, "unit": "MPC steps/s", "trajectories": nbc, "steps": Tc,
+                                                  "p_loss": 0.3, "note": "same loop as closed_loop below, solver and state machines on the host"}
         if world == 1 and not args.no_closed_loop:
             # the same kernel inside the device-resident closed loop over the lossy network (tmpc_mc_run): every step is
             # the solve + the estimator / actuator / plant state machines, 4096 trajectories, p_loss = 0.3 (configs[1])
