@@ -14,10 +14,13 @@ from LinearMPCOverNetworks.TubeTrackingMPC import TubeTrackingMPC, ExtendedTubeT
 pl.set_lp_backend("hip")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+long_horizon = len(sys.argv) > 3 and sys.argv[3] == "long"       # aim at the largest wave-kernel shape (24 variables)
 worst = 0.0
 for case in range(ncase):
     n = int(rng.integers(2, 9)); m = int(rng.integers(1, 3)); N = int(rng.integers(3, 27 if m == 1 else 16))
     fixed = bool(rng.integers(0, 2)); ext = bool(rng.integers(0, 2)) and n <= 4
+    if long_horizon:
+        n, m, N, fixed = int(rng.integers(3, 5)), 1, int(rng.integers(15, 24)), True
     A0 = rng.standard_normal((n, n)); A = rng.uniform(0.7, 1.05) * A0 / np.max(np.abs(np.linalg.eigvals(A0)))
     Bm = rng.standard_normal((n, m))
     Q = np.diag(rng.uniform(0.5, 5.0, n)); R = np.diag(rng.uniform(0.05, 1.0, m))

@@ -23,7 +23,7 @@ def run(name, N, fixed, X, R, B):
         print(f"   {n_:16s} {v:10.0f} ticks  {100*v/t.sum():5.1f}%   per-iter {v/it:8.1f}")
 S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
 idx = np.r_[40, np.random.default_rng(0).integers(0, len(S), 4095)]
-for B in (1, 1024):
+for B in (1, 1024, 4096):
     run("cartpole", 10, True, S[idx, :4].copy(), S[idx, 4:].copy(), B)
 rng = np.random.default_rng(0)
 X = rng.uniform(-1, 1, (1024, 2)) * [3.0, 0.5]; R = np.c_[rng.uniform(-9, 9, 1024), np.zeros(1024)]
