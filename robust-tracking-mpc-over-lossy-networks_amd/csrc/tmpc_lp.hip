@@ -61,13 +61,12 @@ __device__ __forceinline__ double lp_hrow(const LpDevice &p, int rel, int r) {
 // Columns [J0, J1) of M = H' diag(lam / s) H over this lane's rows, summed over the wave into `sums` (packed lower
 // triangle, column-major).  The FIRST sweep also forms H'(d . r_p), H'lam, the gap, |r_p|_inf and max lam.
 template <int D, int J0, int J1, bool FIRST>
-__device__ __forceinline__ void sweep_a(const LpDevice &p, int rel, const double *s_, const double *lam_, const double *gz_, double *red,
-                                        double *sums, double &rpn, double &lmax, int lane) {
+__device__ __forceinline__ void sweep_a(const LpDevice &p, const double *__restrict__ Ht, int rel, const double *s_, const double *lam_,
+                                        const double *gz_, double *red, double *sums, double &rpn, double &lmax, int lane) {
     constexpr int NT = D * (D + 1) / 2;
     constexpr int C0 = lp_col_off<D>(J0), CM = lp_col_off<D>(J1) - C0;
     constexpr int CNT = CM + (FIRST ? 2 * D + 1 : 0);
     const int nr = p.nr, nrp = p.nrp;
-    const double *__restrict__ Ht = p.Ht;
     double acc[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) acc[k] = 0.0;
@@ -112,7 +111,9 @@ __device__ __forceinline__ void sweep_a(const LpDevice &p, int rel, const double
     }
 }
 
-template <int D>
+// STAGED: H' (D x nrp doubles) is copied to LDS once per workgroup and every row sweep reads it from there; otherwise
+// the sweeps read it from global memory (L2)
+template <int D, bool STAGED>
 __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t B, const double *__restrict__ C,
                                                               const int32_t *__restrict__ relax, double *__restrict__ ws,
                                                               double *__restrict__ val, double *__restrict__ xout,
@@ -131,6 +132,12 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
 
     const int d = p.d, nr = p.nr, nrp = p.nrp;
     const double *__restrict__ Ht = p.Ht;
+    if constexpr (STAGED) {
+        double *hl = smem + LP_WPB * L::TOTAL;
+        for (int i = threadIdx.x; i < D * nrp; i += blockDim.x) hl[i] = p.Ht[i];
+        __syncthreads();
+        Ht = hl;
+    }
     const int slot = blockIdx.x * LP_WPB + wave, nslots = gridDim.x * LP_WPB;
     double *s_ = ws + static_cast<size_t>(slot) * LP_ARR * nrp;
     double *lam_ = s_ + nrp, *gz_ = lam_ + nrp, *w_ = gz_ + nrp, *ds_ = w_ + nrp, *dl_ = ds_ + nrp;
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                 // in column blocks, one sweep over the rows each, to stay inside the register file)
                 double rpn = 0.0, lmax = 0.0;
                 [&]<int... Ks>(std::integer_sequence<int, Ks...>) {
-                    (sweep_a<D, LpBlocks<D>::b[Ks], LpBlocks<D>::b[Ks + 1], Ks == 0>(p, rel, s_, lam_, gz_, red, sums, rpn, lmax, lane), ...);
+                    (sweep_a<D, LpBlocks<D>::b[Ks], LpBlocks<D>::b[Ks + 1], Ks == 0>(p, Ht, rel, s_, lam_, gz_, red, sums, rpn, lmax, lane), ...);
                 }(std::make_integer_sequence<int, LpBlocks<D>::n>{});
                 rpn = wave_reduce<OpMax>(rpn);
                 lmax = wave_reduce<OpMax>(lmax);
@@ -526,15 +533,26 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
     }
 }
 
+template <int D, bool STAGED>
+hipError_t launch_lp_ds(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
+                        double *xout, int32_t *status, int32_t *iters, hipStream_t stream) {
+    const size_t lds = (static_cast<size_t>(LpLds<D>::TOTAL) * LP_WPB + (STAGED ? static_cast<size_t>(D) * p.nrp : 0)) * sizeof(double);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lp_kernel<D, STAGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((lp_kernel<D, STAGED>), dim3(nblocks), dim3(WAVE * LP_WPB), lds, stream, p, B, C, relax, ws, val, xout, status, iters);
+    return hipGetLastError();
+}
+
 template <int D>
 hipError_t launch_lp_d(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
                        double *xout, int32_t *status, int32_t *iters, hipStream_t stream) {
-    const size_t lds = static_cast<size_t>(LpLds<D>::TOTAL) * LP_WPB * sizeof(double);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lp_kernel<D>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(lp_kernel<D>, dim3(nblocks), dim3(WAVE * LP_WPB), lds, stream, p, B, C, relax, ws, val, xout, status, iters);
-    return hipGetLastError();
+    // stage H' in LDS when it fits beside the per-wave workspaces (and leaves room for a second workgroup on the CU)
+    const size_t hbytes = static_cast<size_t>(D) * p.nrp * sizeof(double);
+    const size_t base = static_cast<size_t>(LpLds<D>::TOTAL) * LP_WPB * sizeof(double);
+    if (hbytes <= 64 * 1024 && base + hbytes <= 156 * 1024)
+        return launch_lp_ds<D, true>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+    return launch_lp_ds<D, false>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
 }
 
 }  // namespace
