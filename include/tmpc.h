@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define TMPC_ABI_VERSION 2
+/* 1: first cut; 2: projected terminal rows of the packet-received problem (HTP, hTP, rTP); 3: tmpc_lp_batch, TMPC_STATUS_UNBOUNDED */
+#define TMPC_ABI_VERSION 3
 
 /* error codes (function return values) */
 #define TMPC_OK            0
