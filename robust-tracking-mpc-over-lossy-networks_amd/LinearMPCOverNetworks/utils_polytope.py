@@ -25,7 +25,6 @@ changes the resulting sets:
 from __future__ import annotations
 
 import numpy as np
-from scipy.optimize import linprog
 from scipy.spatial import ConvexHull, HalfspaceIntersection
 
 from .polytope_lite import (ABS_TOL, Polytope, as_polytope, box_bounds, lp_max_batch,
@@ -88,11 +87,12 @@ def extreme(poly) -> np.ndarray:
         return np.array([[lo], [hi]])
     # Chebyshev centre as the strictly interior point qhull needs
     nrm = np.linalg.norm(poly.A, axis=1)
-    res = linprog(np.r_[np.zeros(n), -1.0], A_ub=np.c_[poly.A, nrm], b_ub=poly.b,
-                  bounds=[(None, None)] * n + [(0, None)], method="highs")
-    if res.status != 0 or res.x[-1] <= 0:
+    cheb = np.zeros((1, n + 1))
+    cheb[0, -1] = 1.0                                   # max r  s.t.  A x + r |a_i| <= b,  r >= 0
+    val, st, xc = lp_max_batch(cheb, np.r_[np.c_[poly.A, nrm], np.c_[np.zeros((1, n)), -1.0]], np.r_[poly.b, 0.0], want_x=True)
+    if st[0] != 0 or not val[0] > 0:
         raise ValueError("polytope is empty or not full dimensional")
-    hs = HalfspaceIntersection(np.c_[poly.A, -poly.b], res.x[:n])
+    hs = HalfspaceIntersection(np.c_[poly.A, -poly.b], xc[0, :n])
     V = hs.intersections
     V = V[ConvexHull(V).vertices] if V.shape[0] > n + 1 else V
     poly.vertices = V
