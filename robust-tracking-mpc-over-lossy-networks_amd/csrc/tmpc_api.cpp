@@ -351,14 +351,31 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
 
 }  // namespace
 
-// device buffer of tmpc_lp_batch
+// device memory of tmpc_lp_batch: one grow-only allocation per host thread, carved per call (the Gilbert-Tan recursion
+// makes hundreds of small calls; ten hipMalloc / hipFree pairs each cost more than the kernel).  Lives until the
+// process ends.
 namespace {
-struct DevBuf {      // frees on scope exit (this entry point owns no handle)
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
-    template <class T> T *as() { return static_cast<T *>(p); }
+struct LpArena {
+    int device = -1;
+    char *p = nullptr;
+    size_t cap = 0, off = 0;
+    hipError_t reserve(int dev, size_t bytes) {
+        off = 0;
+        if (dev == device && bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0; device = dev;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    template <class T> T *take(size_t count) {
+        T *q = reinterpret_cast<T *>(p + off);
+        off += (count * sizeof(T) + 255) / 256 * 256;
+        return q;
+    }
 };
+thread_local LpArena g_lp_arena;
+size_t lp_round(size_t bytes) { return (bytes + 255) / 256 * 256; }
 }  // namespace
 
 extern "C" {
@@ -756,40 +773,40 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     }
 
     LP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    LP_TRY(hipGetDeviceProperties(&prop, device));
+    static int cu_count[64] = {};                       // hipGetDeviceProperties costs about a millisecond: once per device
+    int n_cu = (device >= 0 && device < 64) ? cu_count[device] : 0;
+    if (n_cu == 0) {
+        LP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+        if (device >= 0 && device < 64) cu_count[device] = n_cu;
+    }
     const int wpb = tmpc::lp_waves_per_block();
     const int64_t want = (B + wpb - 1) / wpb;
-    const int nblocks = static_cast<int>(std::min<int64_t>(want, 2 * static_cast<int64_t>(prop.multiProcessorCount)));
-    DevBuf dHt, dh, drs, dC, drel, dws, dval, dx, dst, dit;
-    LP_TRY(dHt.alloc(Ht.size() * sizeof(double)));
-    LP_TRY(dh.alloc(hs.size() * sizeof(double)));
-    LP_TRY(drs.alloc(rs.size() * sizeof(double)));
-    LP_TRY(dC.alloc(static_cast<size_t>(B) * d * sizeof(double)));
-    LP_TRY(dws.alloc(static_cast<size_t>(nblocks) * wpb * tmpc::lp_workspace_arrays() * nrp * sizeof(double)));
-    LP_TRY(dval.alloc(static_cast<size_t>(B) * sizeof(double)));
-    LP_TRY(dst.alloc(static_cast<size_t>(B) * sizeof(int32_t)));
-    LP_TRY(dit.alloc(static_cast<size_t>(B) * sizeof(int32_t)));
-    if (x) LP_TRY(dx.alloc(static_cast<size_t>(B) * d * sizeof(double)));
-    if (relax) {
-        LP_TRY(drel.alloc(static_cast<size_t>(B) * sizeof(int32_t)));
-        LP_TRY(hipMemcpy(drel.p, relax, static_cast<size_t>(B) * sizeof(int32_t), hipMemcpyHostToDevice));
-    }
-    LP_TRY(hipMemcpy(dHt.p, Ht.data(), Ht.size() * sizeof(double), hipMemcpyHostToDevice));
-    LP_TRY(hipMemcpy(dh.p, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
-    LP_TRY(hipMemcpy(drs.p, rs.data(), rs.size() * sizeof(double), hipMemcpyHostToDevice));
-    LP_TRY(hipMemcpy(dC.p, C, static_cast<size_t>(B) * d * sizeof(double), hipMemcpyHostToDevice));
+    const int nblocks = static_cast<int>(std::min<int64_t>(want, 2 * static_cast<int64_t>(n_cu)));
+    const size_t b = static_cast<size_t>(B), dd = static_cast<size_t>(d);
+    const size_t nws = static_cast<size_t>(nblocks) * wpb * tmpc::lp_workspace_arrays() * nrp;
+    const size_t need = lp_round(Ht.size() * 8) + 2 * lp_round(static_cast<size_t>(nrp) * 8) + 2 * lp_round(b * dd * 8) + lp_round(nws * 8) +
+                        lp_round(b * 8) + 3 * lp_round(b * 4) + 256;
+    LpArena &ar = g_lp_arena;
+    LP_TRY(ar.reserve(device, need));
+    double *dHt = ar.take<double>(Ht.size()), *dh = ar.take<double>(nrp), *drs = ar.take<double>(nrp);
+    double *dC = ar.take<double>(b * dd), *dws = ar.take<double>(nws), *dval = ar.take<double>(b);
+    double *dx = x ? ar.take<double>(b * dd) : nullptr;
+    int32_t *dst = ar.take<int32_t>(b), *dit = ar.take<int32_t>(b), *drel = relax ? ar.take<int32_t>(b) : nullptr;
+    if (relax) LP_TRY(hipMemcpy(drel, relax, b * sizeof(int32_t), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(dHt, Ht.data(), Ht.size() * sizeof(double), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(dh, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(drs, rs.data(), rs.size() * sizeof(double), hipMemcpyHostToDevice));
+    LP_TRY(hipMemcpy(dC, C, b * dd * sizeof(double), hipMemcpyHostToDevice));
     tmpc::LpDevice lp{};
     lp.d = d; lp.nr = nr; lp.nrp = nrp; lp.max_iter = 80;
     lp.tol = 1e-8; lp.relax_by = relax_by; lp.hm = hm;
-    lp.Ht = dHt.as<double>(); lp.h = dh.as<double>(); lp.rscale = drs.as<double>();
-    LP_TRY(tmpc::launch_lp(lp, B, nblocks, dC.as<double>(), relax ? drel.as<int32_t>() : nullptr, dws.as<double>(), dval.as<double>(),
-                           x ? dx.as<double>() : nullptr, dst.as<int32_t>(), dit.as<int32_t>(), nullptr));
+    lp.Ht = dHt; lp.h = dh; lp.rscale = drs;
+    LP_TRY(tmpc::launch_lp(lp, B, nblocks, dC, drel, dws, dval, dx, dst, dit, nullptr));
     LP_TRY(hipDeviceSynchronize());
-    LP_TRY(hipMemcpy(val, dval.p, static_cast<size_t>(B) * sizeof(double), hipMemcpyDeviceToHost));
-    LP_TRY(hipMemcpy(status, dst.p, static_cast<size_t>(B) * sizeof(int32_t), hipMemcpyDeviceToHost));
-    LP_TRY(hipMemcpy(iters, dit.p, static_cast<size_t>(B) * sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (x) LP_TRY(hipMemcpy(x, dx.p, static_cast<size_t>(B) * d * sizeof(double), hipMemcpyDeviceToHost));
+    LP_TRY(hipMemcpy(val, dval, b * sizeof(double), hipMemcpyDeviceToHost));
+    LP_TRY(hipMemcpy(status, dst, b * sizeof(int32_t), hipMemcpyDeviceToHost));
+    LP_TRY(hipMemcpy(iters, dit, b * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (x) LP_TRY(hipMemcpy(x, dx, b * dd * sizeof(double), hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
 
