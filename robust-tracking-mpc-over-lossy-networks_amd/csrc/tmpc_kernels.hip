@@ -274,7 +274,7 @@ __device__ __forceinline__ bool slot_valid(int k, int lane, int nd, int ncc) {
 // The FIRST sweep loads whole rows anyway, so it also forms r_p and accumulates G'(d.r_p), G'lam,
 // the gap and |r_p|_inf.  Nothing per-row is kept besides (s, lam): r_p and 1/s are recomputed by
 // the later sweeps, which is cheaper than carrying them through the register file.
-template <class SH, int J0, int J1, bool FIRST>
+template <class SH, int J0, int J1, bool FIRST, bool CARRY>
 __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw, const double *zv,
                                               const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                               double (&dd)[SH::RD > 0 ? SH::RD : 1],
@@ -296,12 +296,17 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
         if (FIRST) dd[k] = lam[k] * fast_rcp(s[k]);
         const double d = dd[k];
         if (FIRST) {
-            double gz0 = 0.0, gz1 = 0.0;
+            double rpk;
+            if constexpr (CARRY) {
+                rpk = rp[k];                     // carried over from the previous iteration: r_p <- (1 - alpha) r_p
+            } else {
+                double gz0 = 0.0, gz1 = 0.0;
 #pragma unroll
-            for (int j = 0; j + 1 < NV; j += 2) { gz0 += g[j] * zv[j]; gz1 += g[j + 1] * zv[j + 1]; }
-            if (NV & 1) gz0 += g[NV - 1] * zv[NV - 1];
-            const double rpk = (gz0 + gz1) + s[k] - hw[k * WAVE + lane];
-            rp[k] = rpk;
+                for (int j = 0; j + 1 < NV; j += 2) { gz0 += g[j] * zv[j]; gz1 += g[j + 1] * zv[j + 1]; }
+                if (NV & 1) gz0 += g[NV - 1] * zv[NV - 1];
+                rpk = (gz0 + gz1) + s[k] - hw[k * WAVE + lane];
+                rp[k] = rpk;
+            }
             gap_l += s[k] * lam[k];
             rpn_l = fmax(rpn_l, fabs(rpk));
             const double t = d * rpk;
@@ -330,20 +335,20 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, const double *hw
     }
 }
 
-template <class SH, int BI>
+template <class SH, int BI, bool CARRY>
 __device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double *hw, const double *zv,
                                                   const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                                   double (&dd)[SH::RD > 0 ? SH::RD : 1],
                                                   double &gap_l, double &rpn_l, double *red, double *sums, int lane, int nd) {
     using BL = Blocks<SH::NV>;      // the same blocks in both builds: the accumulators are not what overflows the lean build's registers
     if constexpr (BI < BL::n) {
-        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
-        sweep_a_dense_all<SH, BI + 1>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
+        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0, CARRY>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
+        sweep_a_dense_all<SH, BI + 1, CARRY>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
     }
 }
 
 // The FACTORED rows: kc-wide left factor, so W = Hc' D Hc has only KT entries; one pass.
-template <class SH>
+template <class SH, bool CARRY>
 __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double *hw, const double *czv,
                                                  const double (&s)[SH::RT], const double (&lam)[SH::RT], double (&rp)[SH::RT],
                                                  double &gap_l, double &rpn_l, double *red, double *csums, int lane, int ncc) {
@@ -355,11 +360,18 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
     for (int k = SH::RD; k < SH::RT; ++k) {
         const int rc = lane + (k - SH::RD) * WAVE;
         double hc[KC];
-        double gz = 0.0;
+        double rpk;
+        if constexpr (CARRY) {
 #pragma unroll
-        for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * czv[a]; }
-        const double rpk = gz + s[k] - hw[k * WAVE + lane];
-        rp[k] = rpk;
+            for (int a = 0; a < KC; ++a) hc[a] = Hct[a * NCCP + rc];
+            rpk = rp[k];
+        } else {
+            double gz = 0.0;
+#pragma unroll
+            for (int a = 0; a < KC; ++a) { hc[a] = Hct[a * NCCP + rc]; gz += hc[a] * czv[a]; }
+            rpk = gz + s[k] - hw[k * WAVE + lane];
+            rp[k] = rpk;
+        }
         const double rsk = fast_rcp(s[k]);          // padding rows: lam = 0, so d = 0
         gap_l += s[k] * lam[k];
         rpn_l = fmax(rpn_l, fabs(rpk));
@@ -477,6 +489,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         for (int j = 0; j < NV; ++j) qn = fmax(qn, fabs(qv[j]));
 
         double s[RT], lam[RT];
+        // the primal residual is carried from iteration to iteration instead of being formed from
+        // G z in sweep A -- the Newton step gives r_p(z + a dz, s + a ds) = (1 - a) r_p exactly (ds = -r_p - G dz)
+        constexpr bool CARRY = !WARM && NV <= 16;      // (the 24-variable shape keeps its long-tested code path)
+        double rpc[CARRY ? RT : 1];
         double smin = INFINITY;
         {
             double z[NV], cz[KCA];
@@ -514,8 +530,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #pragma unroll
                 for (int k = 0; k < RT; ++k) {
                     const bool valid = slot_valid<SH>(k, lane, nd, ncc);
-                    s[k] = valid ? fmax(s[k], fl) : 1.0;
+                    const double raw = s[k];
+                    s[k] = valid ? fmax(raw, fl) : 1.0;
                     lam[k] = valid ? 1.0 : 0.0;
+                    if constexpr (CARRY) rpc[k] = valid ? s[k] - raw : 0.0;     // r_p = G z + s - h with h - G z = raw
                 }
             }
             double try_tol = qp.tol;
@@ -553,14 +571,20 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 // r_p is kept per row for sweeps B and D; the iterate z and the directions live in LDS only.
                 double gap_l = 0.0, rpn_l = 0.0;
                 double rp[RT];
+                if constexpr (CARRY) {
+#pragma unroll
+                    for (int k = 0; k < RT; ++k) rp[k] = rpc[k];
+                }
                 {
                     double dd[RD > 0 ? RD : 1];
-                    if constexpr (RD > 0) sweep_a_dense_all<SH, 0>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
+                    if constexpr (RD > 0) sweep_a_dense_all<SH, 0, CARRY>(Gt, hw, zv, s, lam, rp, dd, gap_l, rpn_l, red, sums, lane, nd);
                 }
                 if constexpr (KC > 0) {
-                    coords_lds<SH>(Psi, zv, czv, lane);
-                    wave_lds_fence();
-                    sweep_a_factored<SH>(Hct, hw, czv, s, lam, rp, gap_l, rpn_l, red, csums, lane, ncc);
+                    if constexpr (!CARRY) {
+                        coords_lds<SH>(Psi, zv, czv, lane);
+                        wave_lds_fence();
+                    }
+                    sweep_a_factored<SH, CARRY>(Hct, hw, czv, s, lam, rp, gap_l, rpn_l, red, csums, lane, ncc);
                     // fold the factored block into the dense totals: P = W Psi now, Psi' P when the rows are loaded
                     for (int idx = lane; idx < KC * NV; idx += WAVE) {
                         const int a = idx / NV, j = idx - a * NV;
@@ -849,7 +873,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 rho = wave_max(rho);
                 const double alpha = rho > tau ? tau / rho : 1.0;
 #pragma unroll
-                for (int k = 0; k < RT; ++k) { s[k] += alpha * dsv[k]; lam[k] += alpha * dlv[k]; }
+                for (int k = 0; k < RT; ++k) {
+                    s[k] += alpha * dsv[k];
+                    lam[k] += alpha * dlv[k];
+                    if constexpr (CARRY) rpc[k] = (1.0 - alpha) * rp[k];
+                }
                 if (lane < NV) zv[lane] += alpha * dzv[lane];
                 wave_lds_fence();
                 it_done = it + 1;
