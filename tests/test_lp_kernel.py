@@ -254,3 +254,31 @@ def test_random_polytopes_all_dimensions(hip_lib, hip_lp, d, nr):
         Cm = np.r_[rng.standard_normal((40, d)), A[rng.integers(0, nr, 20)]]
     rel = np.full(len(Cm), -1, dtype=np.int32)
     _against_highs(A, b, Cm, rel, hip_lib)
+
+
+@pytest.mark.gpu
+def test_darup_known_answer_with_the_lp_kernel(hip_lib, hip_lp):
+    """The reference's printed known answer k* = 5, 6, 10 (Examples of Set Operations/Example of Approximation of
+    mRPI_Darup.py:50-55) with the container-set LPs solved by the kernel, and the Gilbert-Tan example set
+    (Example of Output Admissible Set Calculation.py scenario: double integrator under LQR, |x| <= 5, |u| <= 1)
+    equal to the HiGHS result."""
+    from LinearMPCOverNetworks.control_lite import dlqr
+    from LinearMPCOverNetworks.polytope_lite import box2poly
+    A = np.array([[1.0, 1.0], [0.0, 1.0]])
+    B = np.array([[0.5], [1.0]])
+    W = box2poly([[-0.1, 0.1]] * 2)
+    X = Polytope(np.r_[np.eye(2), -np.eye(2)], [4, 2, 8, 4])
+    U = box2poly([[-1.0, 1.0]])
+    K, _, _ = dlqr(A, B, np.eye(2), np.eye(1))
+    for eps, k_expected in ((1e-1, 5), (1e-2, 6), (1e-3, 10)):
+        rpi, status = up.calculate_RPI(A - B @ K, W, X, U, K, eps, 50, verbose=False)
+        assert status == 0 and rpi.k_star == k_expected
+    Acl = A - B @ K
+    Xu = Polytope(np.r_[np.eye(2), -np.eye(2), -K, K], np.r_[5.0 * np.ones(4), 1.0, 1.0])
+    got = up.calculate_maximum_admissible_output_set(Acl, Xu, verbose=False)
+    old = pl.set_lp_backend("scipy")
+    try:
+        want = up.calculate_maximum_admissible_output_set(Acl, Xu, verbose=False)
+    finally:
+        pl.set_lp_backend(old)
+    assert got.A.shape == want.A.shape and np.allclose(got.A, want.A, atol=1e-9) and np.allclose(got.b, want.b, atol=1e-8)
