@@ -25,7 +25,7 @@ extern "C" {
 #endif
 
 /* 1: first cut; 2: projected terminal rows of the packet-received problem (HTP, hTP, rTP); 3: tmpc_lp_batch, TMPC_STATUS_UNBOUNDED */
-#define TMPC_ABI_VERSION 3
+#define TMPC_ABI_VERSION 4
 
 /* error codes (function return values) */
 #define TMPC_OK            0
@@ -150,14 +150,6 @@ int tmpc_solve_batch_device(tmpc_handle *h, int64_t B,
                             int32_t *status, int32_t *iters);
 
 /*
- * Experimental: batches of at least `min_batch` instances are iterated by the streaming kernel
- * (16 lanes per QP, row state in an HBM/L2 workspace; csrc/tmpc_stream.hip) and only refined by
- * the one-wave-per-QP kernel.  Off by default (min_batch <= 0 switches it off again); results are
- * the same either way (tests/test_hip_parity.py::test_streaming_path_parity).
- */
-int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch);
-
-/*
  * Which kernel solves a variant.  TMPC_PATH_AUTO (default): the one-wave-per-QP kernel
  * (csrc/tmpc_kernels.hip) when one of its compiled shapes covers the condensed problem, otherwise
  * the workgroup-per-QP kernel (csrc/tmpc_block.hip: nv <= 128, any number of rows, G'DG on the
@@ -170,6 +162,14 @@ int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch);
 #define TMPC_PATH_BLOCK 2
 int tmpc_set_kernel_path(tmpc_handle *h, int path);
 int tmpc_get_kernel_path(const tmpc_handle *h, int variant);
+
+/*
+ * Name of the kernel instantiation that solves a variant on the current path, as it appears (up to the
+ * anonymous-namespace qualifier) in a rocprofv3 kernel trace: "tmpc::solve_kernel<NV,DP,DS,KC,CP,CS,WPB>" (one wavefront
+ * per QP; shape = padded variables, dense paired / single slots, factored width and paired / single slots, waves per
+ * workgroup) or "tmpc::solve_block_kernel<T>" (one workgroup per QP).  The string belongs to the library.
+ */
+const char *tmpc_kernel_name(const tmpc_handle *h, int variant);
 
 /*
  * Device-resident closed loop over a lossy network for B independent trajectories and T time steps: the body

@@ -193,3 +193,69 @@ def kkt_certificate(qp: dict, v: np.ndarray, act_tol: float = 1e-7):
                 r_ineq=float(max(0.0, np.max(-slack))),
                 min_lam=float(lam.min()) if lam.size else 0.0,
                 n_active=int(len(act)), active=act, lam=lam)
+
+
+class SparseTemplate:
+    """The un-condensed QP of one problem/variant with its parameter dependence factored out:
+    P, A, G are constant; q = q0 + Qr ref, b = b0 + Bx x_k, h = h0 + Hx x_k (all affine in the
+    two parameters of TubeTrackingMPC.py:121-122).  Built by 2 nx + 1 calls of build_sparse_qp,
+    so it inherits that function's line-by-line correspondence with the reference."""
+
+    def __init__(self, p: dict, variant: int = 0):
+        nx = int(p["nx"])
+        z = np.zeros(nx)
+        base = build_sparse_qp(p, z, z, variant)
+        self.P, self.A, self.G, self.layout = base["P"], base["A"], base["G"], base["layout"]
+        self.q0, self.b0, self.h0 = base["q"], base["b"], base["h"]
+        self.Qr = np.zeros((len(self.q0), nx))
+        self.Bx = np.zeros((len(self.b0), nx))
+        self.Hx = np.zeros((len(self.h0), nx))
+        self.T = np.asarray(p["T"], dtype=np.float64)
+        for j in range(nx):
+            e = np.zeros(nx)
+            e[j] = 1.0
+            qx = build_sparse_qp(p, e, z, variant)
+            self.Bx[:, j] = qx["b"] - self.b0
+            self.Hx[:, j] = qx["h"] - self.h0
+            self.Qr[:, j] = build_sparse_qp(p, z, e, variant)["q"] - self.q0
+
+    def instance(self, x_k, ref) -> dict:
+        x_k = np.asarray(x_k, dtype=np.float64).reshape(-1)
+        ref = np.asarray(ref, dtype=np.float64).reshape(-1)
+        return dict(P=self.P, q=self.q0 + self.Qr @ ref, c0=float(ref @ self.T @ ref), A=self.A, b=self.b0 + self.Bx @ x_k,
+                    G=self.G, h=self.h0 + self.Hx @ x_k, layout=self.layout)
+
+
+def kkt_certificate_fast(qp: dict, v: np.ndarray, act_tol: float = 1e-7):
+    """kkt_certificate with the multipliers recovered by an unconstrained least-squares fit on the
+    active rows first (degenerate vertices: minimum-norm solution); the bounded fit of
+    kkt_certificate is the fall-back when that fit has a negative multiplier or a residual."""
+    P, q, A, b, G, h = (qp[k] for k in ("P", "q", "A", "b", "G", "h"))
+    slack = h - G @ v
+    scale = np.maximum(1.0, np.abs(h))
+    act = np.flatnonzero(slack <= act_tol * scale)
+    g = P @ v + q
+    Mx = np.c_[A.T, G[act].T]
+    colscale = np.maximum(np.linalg.norm(Mx, axis=0), 1e-300)
+    sol = np.linalg.lstsq(Mx / colscale, -g, rcond=1e-13)[0] / colscale
+    lam = sol[A.shape[0]:]
+    r = g + Mx @ sol
+    qn = max(1.0, np.max(np.abs(q)))
+    if (lam.size == 0 or lam.min() >= -1e-9 * max(1.0, np.abs(lam).max())) and np.max(np.abs(r)) <= 1e-7 * qn:
+        return dict(r_stat=float(np.max(np.abs(r)) / qn),
+                    r_eq=float(np.max(np.abs(A @ v - b))) if A.size else 0.0,
+                    r_ineq=float(max(0.0, np.max(-slack))),
+                    min_lam=float(max(lam.min(), 0.0)) if lam.size else 0.0,      # within -1e-9 |lam|_max of zero: counted as zero
+                    n_active=int(len(act)), active=act, lam=lam)
+    return kkt_certificate(qp, v, act_tol)
+
+
+def lp_infeasible(qp: dict) -> bool:
+    """True iff {A v = b, G v <= h} is empty according to HiGHS (scipy.optimize.linprog, the
+    LP solver the reference itself uses, utils_polytope.py:19) -- the solver-independent
+    counterpart of a TMPC_STATUS_INFEASIBLE answer."""
+    from scipy.optimize import linprog
+    n = qp["G"].shape[1]
+    res = linprog(np.zeros(n), A_ub=qp["G"], b_ub=qp["h"], A_eq=qp["A"] if qp["A"].size else None,
+                  b_eq=qp["b"] if qp["A"].size else None, bounds=[(None, None)] * n, method="highs")
+    return res.status == 2

@@ -12,7 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libtmpc_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _PTR_FIELDS = ["A", "B", "Q", "R", "P", "T", "K", "K_anc",
                "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW", "HTP", "hTP"]
@@ -81,12 +81,12 @@ def lib():
         L.tmpc_solve_batch.restype = C.c_int
         L.tmpc_solve_batch_device.argtypes = sig
         L.tmpc_solve_batch_device.restype = C.c_int
-        L.tmpc_set_stream_min_batch.argtypes = [C.c_void_p, C.c_int64]
-        L.tmpc_set_stream_min_batch.restype = C.c_int
         L.tmpc_set_kernel_path.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_set_kernel_path.restype = C.c_int
         L.tmpc_get_kernel_path.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_get_kernel_path.restype = C.c_int
+        L.tmpc_kernel_name.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_kernel_name.restype = C.c_char_p
         L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 5
         L.tmpc_mc_run.restype = C.c_int
         L.tmpc_mc_set_actuator.argtypes = [C.c_void_p, C.c_int]
@@ -243,10 +243,9 @@ def kernel_ms_total(h: Handle, reset: bool = True):
     return float(ms.value), int(cnt.value)
 
 
-def set_stream_min_batch(h: Handle, min_batch: int):
-    """Experimental streaming path for batches >= min_batch (<= 0: off)."""
-    if lib().tmpc_set_stream_min_batch(h.ptr, int(min_batch)) != 0:
-        raise RuntimeError(h.error())
+def kernel_name(h: Handle, variant: int = 0) -> str:
+    """Name of the kernel instantiation that solves `variant` (as in a rocprofv3 kernel trace)."""
+    return lib().tmpc_kernel_name(h.ptr, int(variant)).decode()
 
 
 KERNEL_PATHS = {"auto": 0, "wave": 1, "block": 2}

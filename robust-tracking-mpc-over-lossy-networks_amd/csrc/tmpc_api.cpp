@@ -23,8 +23,6 @@ struct Variant {
     tmpc::Condensed c;
     tmpc::DeviceQP d{};
     tmpc::KernelShape shape;
-    tmpc::StreamQP sq{};
-    bool stream_ok = false;
     bool wave_ok = false;        // a compiled one-wave-per-QP shape covers this variant
     tmpc::DeviceQP db{};         // same model with Hs / Hinv padded for the block kernel
     tmpc::BlockQP bq{};
@@ -46,11 +44,6 @@ struct tmpc_handle {
     // event pairs of the launches since the last tmpc_kernel_ms_total(reset): per-launch device time
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
     size_t pool_used = 0;
-    // workspace of the streaming path: (s, lambda) per row, z, hand-over status / iteration count
-    int64_t ws_cap = 0;
-    int ws_ncp = 0;
-    double *ws_s = nullptr, *ws_lam = nullptr, *ws_z = nullptr;
-    int32_t *ws_stat = nullptr, *ws_it = nullptr;
     std::vector<double> hA, hB, hK, hKanc;   // host copies for the closed-loop entry point
     // closed-loop state lives in one grow-only arena (25 hipMalloc / hipFree per call cost several milliseconds)
     char *mc_arena = nullptr;
@@ -62,7 +55,6 @@ struct tmpc_handle {
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
     int blk_ncp = 0;
     double *blk_ws = nullptr;
-    int64_t stream_min_batch = INT64_MAX;   // streaming path is opt-in (tmpc_set_stream_min_batch); see DESIGN.md 5.3
     // staging buffers for the host-pointer entry point
     int64_t cap = 0;
     double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
@@ -122,55 +114,88 @@ int upload_common(tmpc_handle *h, Variant &v, const tmpc_problem &p, tmpc::Devic
     return TMPC_OK;
 }
 
-// one-wave-per-QP path (tmpc_kernels.hip): slot layout, factored terminal block
+// one-wave-per-QP path (tmpc_kernels.hip): functionals (a row and, where it exists, its mirror row) in 64-wide slots of four
+// kinds -- dense paired, dense single, factored paired, factored single -- and per row side the right-hand side data
 int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const tmpc::Condensed &c = v.c;
-    int nd = c.nd, ncc = c.ncc, kc = c.kc;
-    if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) {
-        nd = c.nc; ncc = 0; kc = 0;                       // no factored shape compiled: all rows dense
-        if (!tmpc::pick_config(c.nv, nd, kc, ncc, &v.shape)) return TMPC_OK;      // wave_ok stays false
+    const int nx = c.nx;
+    auto in_fact = [&](int r) { return c.ncc > 0 && r >= c.fb0 && r < c.fb0 + c.ncc; };
+    // three layouts, most structured first: pairs + factored block; single rows + factored block; single rows, all dense
+    bool use_pairs = false, use_fact = false;
+    std::vector<std::pair<int, int>> dpair, cpair;     // (row, mirror row)
+    std::vector<int> dsing, csing;
+    bool found = false;
+    for (int attempt = 0; attempt < 3 && !found; ++attempt) {
+        use_pairs = attempt == 0;
+        use_fact = attempt <= 1 && c.ncc > 0;
+        dpair.clear(); cpair.clear(); dsing.clear(); csing.clear();
+        for (int r = 0; r < c.nc; ++r) {
+            const bool f = use_fact && in_fact(r);
+            const int q = (use_pairs && !c.mirror.empty()) ? c.mirror[r] : -1;
+            if (q >= 0 && q < r) continue;                       // second member of a pair: placed with the first
+            if (q >= 0) (f ? cpair : dpair).emplace_back(r, q);
+            else (f ? csing : dsing).push_back(r);
+        }
+        found = tmpc::pick_config(c.nv, static_cast<int>(dpair.size()), static_cast<int>(dsing.size()), use_fact ? c.kc : 0,
+                                  static_cast<int>(cpair.size()), static_cast<int>(csing.size()), &v.shape);
     }
-    const int NVP = v.shape.nvp, NDP = v.shape.rd * 64, KCP = v.shape.kcp, NCCP = v.shape.rc * 64, nx = c.nx;
-    const int slots = (v.shape.rd + v.shape.rc) * 64;
-    std::vector<double> Gt(static_cast<size_t>(NVP) * NDP, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
-        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), g0p(slots, 1.0), Esp(static_cast<size_t>(slots) * nx, 0.0);
-    for (int r = 0; r < nd; ++r)
-        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NDP + r] = c.Gs(r, j);
-    for (int r = 0; r < ncc; ++r)
-        for (int a = 0; a < kc; ++a) Hct[static_cast<size_t>(a) * NCCP + r] = c.Hc(r, a);
+    if (!found) return TMPC_OK;                                  // wave_ok stays false: the block kernel takes the variant
+    const int NVP = v.shape.nvp, DP = v.shape.dp, DS = v.shape.ds, KCP = v.shape.kcp, CP = v.shape.cp, CS = v.shape.cs;
+    const int NDP = (DP + DS) * 64, NCCP = (CP + CS) * 64, RS = 2 * DP + DS + 2 * CP + CS;
+    const int kc = use_fact ? c.kc : 0;
+    std::vector<double> Gt(static_cast<size_t>(NVP) * NDP + 1, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
+        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), g0p(static_cast<size_t>(RS) * 64, 1.0), Esp(static_cast<size_t>(RS) * 64 * nx, 0.0);
+    std::vector<uint32_t> vmask(64, 0u);
+    std::vector<int32_t> row_of(static_cast<size_t>(RS) * 64, -1);
+    auto put_side = [&](int side, int lane, int row) {
+        const size_t sl = static_cast<size_t>(side) * 64 + lane;
+        g0p[sl] = c.g0s[row];
+        for (int j = 0; j < nx; ++j) Esp[sl * nx + j] = c.Es(row, j);
+        vmask[lane] |= 1u << side;
+        row_of[sl] = row;
+    };
+    auto put_dense = [&](int fslot, int lane, int row) {
+        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NDP + fslot * 64 + lane] = c.Gs(row, j);
+    };
+    auto put_fact = [&](int fslot, int lane, int row) {
+        for (int a = 0; a < kc; ++a) Hct[static_cast<size_t>(a) * NCCP + fslot * 64 + lane] = c.Hc(row - c.fb0, a);
+    };
+    for (size_t f = 0; f < dpair.size(); ++f) {
+        const int k = static_cast<int>(f / 64), lane = static_cast<int>(f % 64);
+        put_dense(k, lane, dpair[f].first);
+        put_side(2 * k, lane, dpair[f].first);
+        put_side(2 * k + 1, lane, dpair[f].second);
+    }
+    for (size_t f = 0; f < dsing.size(); ++f) {
+        const int k = static_cast<int>(f / 64), lane = static_cast<int>(f % 64);
+        put_dense(DP + k, lane, dsing[f]);
+        put_side(2 * DP + k, lane, dsing[f]);
+    }
+    const int cb = 2 * DP + DS;
+    for (size_t f = 0; f < cpair.size(); ++f) {
+        const int k = static_cast<int>(f / 64), lane = static_cast<int>(f % 64);
+        put_fact(k, lane, cpair[f].first);
+        put_side(cb + 2 * k, lane, cpair[f].first);
+        put_side(cb + 2 * k + 1, lane, cpair[f].second);
+    }
+    for (size_t f = 0; f < csing.size(); ++f) {
+        const int k = static_cast<int>(f / 64), lane = static_cast<int>(f % 64);
+        put_fact(CP + k, lane, csing[f]);
+        put_side(cb + 2 * CP + k, lane, csing[f]);
+    }
     for (int a = 0; a < kc; ++a)
         for (int j = 0; j < c.nv; ++j) Psi[static_cast<size_t>(a) * NVP + j] = c.Psi(a, j);
-    for (int r = 0; r < c.nc; ++r) {
-        const int slot = r < nd ? r : NDP + (r - nd);
-        g0p[slot] = c.g0s[r];
-        for (int j = 0; j < nx; ++j) Esp[static_cast<size_t>(slot) * nx + j] = c.Es(r, j);
-    }
     tmpc::DeviceQP &d = v.d;
     int rc;
     if ((rc = upload_common(h, v, p, d, NVP))) return rc;
-    d.nd = nd; d.ncc = ncc; d.kc = kc;
+    d.nd = use_fact ? c.nd : c.nc; d.ncc = use_fact ? c.ncc : 0; d.kc = kc;
     if ((rc = upload(h, v, Gt.data(), Gt.size(), &d.Gt))) return rc;
     if ((rc = upload(h, v, Hct.data(), Hct.size(), &d.Hct))) return rc;
     if ((rc = upload(h, v, Psi.data(), Psi.size(), &d.Psi))) return rc;
     if ((rc = upload(h, v, g0p.data(), g0p.size(), &d.g0p))) return rc;
     if ((rc = upload(h, v, Esp.data(), Esp.size(), &d.Esp))) return rc;
-    // streaming path: every row dense, row order of Condensed::Gs
-    {
-        const int ncp = (c.nc + 63) / 64 * 64;
-        v.stream_ok = tmpc::stream_supported(NVP, ncp, nx);
-        if (v.stream_ok) {
-            std::vector<double> Gd(static_cast<size_t>(NVP) * ncp, 0.0), g0d(ncp, 1.0), Esd(static_cast<size_t>(ncp) * nx, 0.0);
-            for (int r = 0; r < c.nc; ++r) {
-                for (int j = 0; j < c.nv; ++j) Gd[static_cast<size_t>(j) * ncp + r] = c.Gs(r, j);
-                g0d[r] = c.g0s[r];
-                for (int j = 0; j < nx; ++j) Esd[static_cast<size_t>(r) * nx + j] = c.Es(r, j);
-            }
-            v.sq.ncp = ncp;
-            if ((rc = upload(h, v, Gd.data(), Gd.size(), &v.sq.Gd))) return rc;
-            if ((rc = upload(h, v, g0d.data(), g0d.size(), &v.sq.g0d))) return rc;
-            if ((rc = upload(h, v, Esd.data(), Esd.size(), &v.sq.Esd))) return rc;
-        }
-    }
+    if ((rc = upload(h, v, vmask.data(), vmask.size(), &d.vmask))) return rc;
+    if ((rc = upload(h, v, row_of.data(), row_of.size(), &d.row_of))) return rc;
 #ifdef TMPC_STAMPS
     {
         void *dbgp = nullptr;
@@ -208,6 +233,7 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload_common(h, v, p, v.db, NVP))) return rc;
     v.db.nd = c.nc; v.db.ncc = 0; v.db.kc = 0;
     v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = nullptr;
+    v.db.vmask = nullptr; v.db.row_of = nullptr;
     v.bq.ncp = ncp;
     // the Z rows of a free initial state touch x_0 only: the block kernel treats them as a narrow class when there are many
     v.bq.nz4 = (c.off_x0 >= 0 && c.nz >= 256) ? (c.nz / 4) * 4 : 0;
@@ -292,7 +318,8 @@ int ensure_staging(tmpc_handle *h, int64_t B) {
 }
 
 int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
-            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters) {
+            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, const int32_t *ws_in = nullptr,
+            int32_t *ws_out = nullptr) {
     hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
     if (h->pool_used < 4096) {
         if (h->pool_used == h->pool.size()) {
@@ -318,31 +345,8 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
                                           xu_ss, x_nom, status, iters, h->stream));
             continue;
         }
-        tmpc::WarmStart warm{};
-        if (v.stream_ok && B >= h->stream_min_batch) {
-            // large batch: 16-lane-per-QP streaming iteration first, refinement by the wave-per-QP kernel
-            if (B > h->ws_cap || v.sq.ncp > h->ws_ncp) {
-                HIP_TRY(h, hipStreamSynchronize(h->stream));
-                void *old_p[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it};
-                for (void *q2 : old_p) if (q2) (void)hipFree(q2);
-                int ncp_max = 0;
-                for (int kk = 0; kk < h->nvariants; ++kk) ncp_max = std::max(ncp_max, h->v[kk].sq.ncp);
-                const size_t b2 = static_cast<size_t>(B);
-                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_s), b2 * ncp_max * sizeof(double)));
-                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_lam), b2 * ncp_max * sizeof(double)));
-                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_z), b2 * 32 * sizeof(double)));
-                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_stat), b2 * sizeof(int32_t)));
-                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->ws_it), b2 * sizeof(int32_t)));
-                h->ws_cap = B;
-                h->ws_ncp = ncp_max;
-            }
-            HIP_TRY(h, tmpc::launch_stream(v.d, v.sq, v.shape.nvp, k, B, x_k, ref, variant, h->ws_s, h->ws_lam, h->ws_z,
-                                           h->ws_stat, h->ws_it, h->stream));
-            warm.s = h->ws_s; warm.lam = h->ws_lam; warm.z = h->ws_z; warm.stat = h->ws_stat; warm.it = h->ws_it;
-            warm.ncp = v.sq.ncp;
-        }
-        HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, warm, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
-                                      iters, h->n_cu, h->stream));
+        HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
+                                      iters, ws_in, ws_out, h->n_cu, h->stream));
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -451,7 +455,7 @@ void tmpc_destroy(tmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
     {
-        void *wsp[] = {h->ws_s, h->ws_lam, h->ws_z, h->ws_stat, h->ws_it, h->blk_ws, h->mc_arena};
+        void *wsp[] = {h->blk_ws, h->mc_arena};
         for (void *q2 : wsp) if (q2) (void)hipFree(q2);
     }
     for (int k = 0; k < 2; ++k)
@@ -500,12 +504,6 @@ int tmpc_solve_batch(tmpc_handle *h, int64_t B, const double *x_k, const double 
     return TMPC_OK;
 }
 
-int tmpc_set_stream_min_batch(tmpc_handle *h, int64_t min_batch) {
-    if (!h) return TMPC_E_INVALID;
-    h->stream_min_batch = min_batch > 0 ? min_batch : INT64_MAX;
-    return TMPC_OK;
-}
-
 int tmpc_set_kernel_path(tmpc_handle *h, int path) {
     if (!h) return TMPC_E_INVALID;
     if (path != TMPC_PATH_AUTO && path != TMPC_PATH_WAVE && path != TMPC_PATH_BLOCK) { h->err = "tmpc_set_kernel_path: unknown path"; return TMPC_E_INVALID; }
@@ -521,6 +519,17 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
     if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
     if (h->device < 0) return TMPC_PATH_AUTO;
     return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;
+}
+
+const char *tmpc_kernel_name(const tmpc_handle *h, int variant) {
+    if (!h || variant < 0 || variant >= h->nvariants) return "";
+    const Variant &v = h->v[variant];
+    if (use_block(h, v)) {
+        static const char *names[] = {"", "tmpc::solve_block_kernel<1>", "tmpc::solve_block_kernel<2>", "", "tmpc::solve_block_kernel<4>",
+                                      "", "", "", "tmpc::solve_block_kernel<8>"};
+        return (v.tiles >= 0 && v.tiles <= 8) ? names[v.tiles] : "";
+    }
+    return tmpc::kernel_name(v.shape);
 }
 
 int tmpc_mc_set_actuator(tmpc_handle *h, int kind) {

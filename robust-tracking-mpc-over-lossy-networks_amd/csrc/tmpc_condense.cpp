@@ -200,7 +200,7 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     // ---- constraints, in the reference's order
     std::vector<std::vector<double>> Grow, Erow;
     std::vector<double> hrow, hcn;
-    std::vector<int> rowblk, rowidx;      // block id (1 = terminal) and row number inside its block
+    std::vector<int> rowblk, rowidx;      // block id (1 = terminal, 2 = initial state) and row number inside its block
     int cur_blk = 0;
     auto add_rows = [&](const Mat &Hc, const double *hc, const Aff &sig) {
         const Mat G = mul(Hc, sig.L), E = mul(Hc, sig.Dx);
@@ -221,7 +221,9 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         // Hz (x_k - x_0) <= hz  (TubeTrackingMPC.py:132 / :278)
         Aff xk(nx, nv, nx);
         xk.Dx = eye(nx);
+        cur_blk = 2;
         add_rows(from_ptr(HZp, rz, nx), hZp, sub(xk, x[0]));
+        cur_blk = 0;
     }
     const Mat Hx = from_ptr(p.Hx, p.rx, nx), Hu = from_ptr(p.Hu, p.ru, nu);
     for (int i = 0; i < N; ++i) {
@@ -284,22 +286,34 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         else if (std::sqrt(en) > thr) par.push_back(r);
         else if (hrow[r] < -1e-9 * (1.0 + std::fabs(hrow[r]))) c.always_infeasible = true;
     }
-    // the terminal block is kept in factored form when that pays (many rows, small rank); its rows
-    // then go last.  Everything else, in the reference's order, is "dense".
+    // one block is kept in factored form when that pays (many rows, small rank): the terminal block (its rows then go
+    // last) or, when it is the larger one, the initial-state block (its rows stay first).  Everything else, in the
+    // reference's order, is "dense".
+    int fblk = 0;          // 0: nothing factored
     {
-        int nterm = 0;
-        for (int r : keep) nterm += rowblk[r] == 1;
-        const bool compact = nterm >= 64 && kT + 3 <= nv;
-        std::vector<int> dense_rows, term_rows;
-        for (int r : keep) ((compact && rowblk[r] == 1) ? term_rows : dense_rows).push_back(r);
-        keep = dense_rows;
-        keep.insert(keep.end(), term_rows.begin(), term_rows.end());
+        int nterm = 0, ninit = 0;
+        for (int r : keep) { nterm += rowblk[r] == 1; ninit += rowblk[r] == 2; }
+        const bool term_ok = nterm >= 64 && kT + 3 <= nv;
+        const bool init_ok = !fixed && ninit >= 64 && nx + 3 <= nv;
+        if (term_ok && (!init_ok || nterm >= ninit)) fblk = 1;
+        else if (init_ok) fblk = 2;
+        std::vector<int> dense_rows, fact_rows;
+        for (int r : keep) ((fblk != 0 && rowblk[r] == fblk) ? fact_rows : dense_rows).push_back(r);
         c.nz = 0;
         if (!fixed)
-            for (int r : dense_rows) { if (r < rz) ++c.nz; else break; }      // they come first in the reference's order
+            for (int r : keep) { if (rowblk[r] == 2) ++c.nz; else break; }      // they come first in the reference's order
+        if (fblk == 2) {
+            keep = fact_rows;
+            keep.insert(keep.end(), dense_rows.begin(), dense_rows.end());
+            c.fb0 = 0;
+        } else {
+            keep = dense_rows;
+            keep.insert(keep.end(), fact_rows.begin(), fact_rows.end());
+            c.fb0 = static_cast<int>(dense_rows.size());
+        }
         c.nd = static_cast<int>(dense_rows.size());
-        c.ncc = static_cast<int>(term_rows.size());
-        c.kc = compact ? kT : 0;
+        c.ncc = static_cast<int>(fact_rows.size());
+        c.kc = fblk == 1 ? kT : (fblk == 2 ? nx : 0);
     }
     c.nc = static_cast<int>(keep.size());
     c.npar = static_cast<int>(par.size());
@@ -338,21 +352,48 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     if (c.ncc > 0) {
         c.Psi = Mat(c.kc, nv);
         c.Hc = Mat(c.ncc, c.kc);
-        for (int a = 0; a < c.kc; ++a) for (int j = 0; j < nv; ++j) c.Psi(a, j) = PsiT(a, j) * c.Dv[j];
+        if (fblk == 1) {
+            for (int a = 0; a < c.kc; ++a) for (int j = 0; j < nv; ++j) c.Psi(a, j) = PsiT(a, j) * c.Dv[j];
+        } else {
+            // Hz (x_k - x_0): the rows are -Hz on the x_0 block of z
+            for (int a = 0; a < nx; ++a) c.Psi(a, c.off_x0 + a) = c.Dv[c.off_x0 + a];
+        }
         double worst = 0;
         for (int r = 0; r < c.ncc; ++r) {
-            const int src = rowidx[keep[c.nd + r]];
+            const int src = rowidx[keep[c.fb0 + r]];
             double n2 = 0;
-            for (int j = 0; j < nv; ++j) { const double v = c.G(c.nd + r, j) * c.Dv[j]; n2 += v * v; }
+            for (int j = 0; j < nv; ++j) { const double v = c.G(c.fb0 + r, j) * c.Dv[j]; n2 += v * v; }
             const double rn = std::sqrt(n2);
-            for (int a = 0; a < c.kc; ++a) c.Hc(r, a) = HcT(src, a) / rn;
+            for (int a = 0; a < c.kc; ++a) c.Hc(r, a) = (fblk == 1 ? HcT(src, a) : -HZp[static_cast<size_t>(src) * nx + a]) / rn;
             for (int j = 0; j < nv; ++j) {           // consistency of the factorisation with the dense rows
                 double v = 0;
                 for (int a = 0; a < c.kc; ++a) v += c.Hc(r, a) * c.Psi(a, j);
-                worst = std::max(worst, std::fabs(v - c.Gs(c.nd + r, j)));
+                worst = std::max(worst, std::fabs(v - c.Gs(c.fb0 + r, j)));
             }
         }
-        if (worst > 1e-10) return "internal error: factored terminal block does not reproduce its rows";
+        if (worst > 1e-10) return "internal error: factored block does not reproduce its rows";
+    }
+    // mirror rows (the two sides of box-type constraints), within the dense class and within the factored class
+    c.mirror.assign(c.nc, -1);
+    if (nv <= 32) {
+        auto in_fact = [&](int r) { return c.ncc > 0 && r >= c.fb0 && r < c.fb0 + c.ncc; };
+        for (int r = 0; r < c.nc; ++r) {
+            if (c.mirror[r] >= 0) continue;
+            for (int q = r + 1; q < c.nc; ++q) {
+                if (c.mirror[q] >= 0 || in_fact(q) != in_fact(r)) continue;
+                double dmax = 0;
+                for (int j = 0; j < nv && dmax <= 1e-13; ++j) dmax = std::max(dmax, std::fabs(c.Gs(r, j) + c.Gs(q, j)));
+                if (dmax > 1e-13) continue;
+                if (in_fact(r)) {      // the factored rows are applied through Hc: require the mirror there as well
+                    double hmax = 0;
+                    for (int a = 0; a < c.kc; ++a) hmax = std::max(hmax, std::fabs(c.Hc(r - c.fb0, a) + c.Hc(q - c.fb0, a)));
+                    if (hmax > 1e-13) continue;
+                }
+                c.mirror[r] = q;
+                c.mirror[q] = r;
+                break;
+            }
+        }
     }
     // Hs^-1 (used for the unconstrained minimiser and by the active-set refinement)
     c.Hinv = Mat(nv, nv);

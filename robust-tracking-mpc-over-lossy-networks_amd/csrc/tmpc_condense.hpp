@@ -46,14 +46,20 @@ struct Condensed {
     std::vector<double> Dv;
     Mat Hs, Hinv, Gs, Es, F1s, F2s;
     std::vector<double> g0s;
-    // Row order: the first `nd` rows are "dense" (general rows of Gs); the last `ncc` rows are the
-    // terminal block in factored form  Gs[nd + r, :] = Hc(r, :) * Psi :  the terminal inequality
-    // (TubeTrackingMPC.py:149) acts on [x_N; x_bar; u_bar] only, i.e. on kc = nx + nth (+ nu)
-    // combinations of z, so its rows have rank kc << nv.  ncc == 0 when the block is kept dense.
-    int nd = 0, ncc = 0, kc = 0;
+    // Row order.  One block of rows of small rank may be kept in FACTORED form  Gs[fb0 + r, :] = Hc(r, :) * Psi, r < ncc:
+    //   * the terminal inequality (TubeTrackingMPC.py:149) acts on [x_N; x_bar; u_bar] only, i.e. on kc = nx + nth (+ nu)
+    //     combinations of z; its rows then go LAST (fb0 = nd);
+    //   * the initial-state rows Hz (x_k - x_0) <= hz of a free x_0 (:132, :278) act on x_0 only (kc = nx); they come FIRST
+    //     in the reference's order and stay there (fb0 = 0) -- chosen when they outnumber the terminal rows (the
+    //     packet-received problem: 854 rows of Z (-) W against the projected terminal rows).
+    // The other nd = nc - ncc rows are "dense" (general rows of Gs), in the reference's order.  ncc == 0: nothing factored.
+    int nd = 0, ncc = 0, kc = 0, fb0 = 0;
     int nz = 0;        // the first nz rows are the initial-state rows Hz (x_k - x_0) <= hz: they act on the x_0 block of z only
     Mat Psi;     // kc x nv, scaled with Dv
     Mat Hc;      // ncc x kc, rows scaled like Gs
+    // mirror[r] = q when scaled row q is the exact mirror image of row r (Gs_q = -Gs_r: the two sides of a box-type
+    // constraint) and both lie in the same class (dense / factored); -1 otherwise.  Filled for nv <= 32 only.
+    std::vector<int> mirror;
 };
 
 // Builds variant 0 (base problem) or 1 (packet-received problem).  Returns "" on

@@ -10,9 +10,14 @@
 
 namespace tmpc {
 
-// All pointers are device pointers owned by the handle.  The kernel instantiation chosen for a
-// variant is (NVP, RD, KCP, RC): padded variable count, 64-row slots of dense rows, padded width
-// and 64-row slots of the factored terminal block (KCP = RC = 0: everything dense).
+// Working set handed from one solve to the next (closed loop): per instance WS_STRIDE ints = [m, row ids ...]; a row id is
+// (row side) * 64 + lane in the wave kernel's slot layout.  m = 0: nothing to start from.
+constexpr int WS_CAP = 36;       // largest working set the refinement handles (24 for the shapes with NV <= 24)
+constexpr int WS_STRIDE = 40;
+
+// All pointers are device pointers owned by the handle.  The wave kernel's instantiation for a variant is
+// (NVP, DP, DS, KCP, CP, CS): padded variable count; 64-functional slots of dense paired / dense single rows; padded width
+// of the factored block and its paired / single slots (KCP = CP = CS = 0: everything dense).  See tmpc_kernels.hip.
 struct DeviceQP {
     int nx, nu, N;
     int nv, nc, npar, nth;
@@ -20,15 +25,17 @@ struct DeviceQP {
     int off_theta, off_x0, off_aux;
     int max_iter, always_infeasible;
     double tol;
-    const double *Gt;     // [NVP][RD*64]   scaled dense rows, transposed, zero padded
-    const double *Hct;    // [KCP][RC*64]   factored rows' left factor, transposed, zero padded
-    const double *Psi;    // [KCP][NVP]     factored rows' right factor
-    const double *Hs;     // [NVP][NVP]     scaled Hessian, identity on the padding
+    const double *Gt;     // [NVP][(DP+DS)*64]   dense functionals (paired slots first), scaled, transposed, zero padded
+    const double *Hct;    // [KCP][(CP+CS)*64]   factored functionals' left factor, transposed, zero padded
+    const double *Psi;    // [KCP][NVP]          factored rows' right factor
+    const double *Hs;     // [NVP][NVP]          scaled Hessian, identity on the padding
     const double *Hinv;   // [NVP][NVP]
     const double *F1s;    // [nv][nx]
     const double *F2s;    // [nv][nx]
-    const double *g0p;    // [(RD+RC)*64]      right-hand side offsets, slot layout (padding rows: 1)
-    const double *Esp;    // [(RD+RC)*64][nx]  right-hand side dependence on x_k, slot layout
+    const double *g0p;    // [RS*64]       right-hand side offsets per row side, slot layout (padding: 1); RS = 2 DP + DS + 2 CP + CS
+    const double *Esp;    // [RS*64][nx]   right-hand side dependence on x_k, slot layout
+    const uint32_t *vmask;   // [64]       bit i of entry l: row side i of lane l is a real row
+    const int32_t *row_of;   // [RS*64]    row (order of Condensed::Gs) behind each row side, -1: padding
     const double *gp0;    // [npar]
     const double *Ep;     // [npar][nx]
     const double *Dv;     // [nv]
@@ -36,21 +43,6 @@ struct DeviceQP {
     const double *A;      // [nx][nx]
     const double *B;      // [nx][nu]
     long long *dbg;       // diagnostic builds only (TMPC_STAMPS); nullptr otherwise
-};
-
-// Streaming path (tmpc_stream.hip): all rows dense, in the row order of Condensed::Gs
-struct StreamQP {
-    int ncp;              // row stride of the workspace and of Gd (multiple of 64, >= nc)
-    const double *Gd;     // [NVP][ncp] scaled G, transposed, zero padded
-    const double *g0d;    // [ncp]
-    const double *Esd;    // [ncp][nx]
-};
-
-// State handed from the streaming kernel to solve_kernel (warm mode); z == nullptr: cold start
-struct WarmStart {
-    const double *s, *lam, *z;
-    const int32_t *stat, *it;
-    int ncp;
 };
 
 // Block path (tmpc_block.hip): all rows dense, row order of Condensed::Gs, nv padded to 16 * tiles
@@ -65,17 +57,20 @@ struct BlockQP {
 };
 
 struct KernelShape {
-    int nvp = 0, rd = 0, kcp = 0, rc = 0;
+    int nvp = 0, dp = 0, ds = 0, kcp = 0, cp = 0, cs = 0;
 };
 
-// Chooses the smallest compiled shape that covers the variant; false if none does.  When no
-// factored shape fits, the caller may retry with everything dense (kc = 0, nd = nc).
-bool pick_config(int nv, int nd, int kc, int ncc, KernelShape *shape);
+// Chooses the cheapest compiled shape that covers a variant with nd2 / nd1 dense paired / single functionals and nc2 / nc1
+// factored ones of width kc; false if none does.
+bool pick_config(int nv, int nd2, int nd1, int kc, int nc2, int nc1, KernelShape *shape);
 size_t lds_bytes(const KernelShape &shape);
+const char *kernel_name(const KernelShape &shape);
 
-hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, const WarmStart &warm, int variant_id, int64_t B,
+// ws_in / ws_out: optional working sets (WS_STRIDE ints per instance), see above
+hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
-                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int n_cu, hipStream_t stream);
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out,
+                        int n_cu, hipStream_t stream);
 
 // Block path: tiles = NVP / 16 in {1, 2, 4, 8} (0: nv > 128, unsupported); workspace = blocks * rows * ncp doubles
 int block_tiles(int nv);
@@ -126,11 +121,5 @@ int lp_waves_per_block();
 int lp_workspace_arrays();
 hipError_t launch_lp(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
                      double *xout, int32_t *status, int32_t *iters, hipStream_t stream);
-
-size_t stream_lds_bytes(int nvp, int ncp, int nx);
-bool stream_supported(int nvp, int ncp, int nx);
-hipError_t launch_stream(const DeviceQP &qp, const StreamQP &sq, int nvp, int variant_id, int64_t B, const double *x_k,
-                         const double *ref, const uint8_t *variant, double *ws_s, double *ws_lam, double *ws_z,
-                         int32_t *ws_stat, int32_t *ws_iters, hipStream_t stream);
 
 }  // namespace tmpc

@@ -164,3 +164,50 @@ def test_reference_stream_order():
                            rng_w.uniform(-wb[2], wb[2]), rng_w.uniform(-wb[3], wb[3])]
                 assert np.array_equal(w[k, t], wt)
             k += 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extended", [False, True])
+def test_config4_sweep_on_device(hip_lib, extended):
+    """BASELINE config 4 at reduced N_MC: the sweep of results_linear_system.py:147-301 -- p_loss = 0, 0.1 ... 0.9,
+    T = 250 steps, N = 20, reference 0.5 -- through montecarlo.mc_sweep with the state machines on the device
+    (tmpc_mc_run), against the same sweep with the numpy state machines around the same GPU solver.  Same table, row for
+    row; no tube violation; every solve optimal (what the reference's experiment reports for the tube MPC)."""
+    mpc, w = common.make_mpc("cartpole", 20, True, extended=extended, create=True)
+    p_loss = np.arange(10) / 10.0                                          # results_linear_system.py:149
+    n_mc, T = 6, 250
+    dev, pi = montecarlo.mc_sweep(mpc, w, p_loss, n_mc, T, 0.5, extended=extended, on_device=True)
+    host, pi2 = montecarlo.mc_sweep(mpc, w, p_loss, n_mc, T, 0.5, extended=extended, on_device=False)
+    assert dev.shape == (60, 3) and np.array_equal(pi, pi2) and sorted(set(pi)) == list(range(10))
+    assert np.all(dev[:, 1] == 0) and np.all(dev[:, 2] == 0)
+    np.testing.assert_allclose(dev[:, 0], host[:, 0], atol=1e-10, rtol=0)
+    assert np.array_equal(dev[:, 1:], host[:, 1:])
+    # the loss-free trajectories track best, and losing 90 % of the packets still keeps the loop inside the tube
+    assert dev[pi == 0, 0].mean() <= dev[pi == 9, 0].mean() + 1e-12
+    # a sharded sweep (two halves, as two ranks would run it) gives the same rows
+    lo, hi = montecarlo.shard_bounds(60, 1, 2)
+    th, ga, wd = montecarlo.draw_realisations(hi - lo, T, w["w_bound"], first=lo)
+    half = mpc.run_closed_loop(p_loss[pi[lo:hi]], np.full(T, 0.5), th, ga, wd, extended=extended)
+    np.testing.assert_allclose(half["tracking_error"], dev[lo:hi, 0], atol=1e-12, rtol=0)
+
+
+@pytest.mark.gpu
+def test_reference_streams_replay_on_device(hip_lib):
+    """The reference's own realisations -- generators 679 / 347 / 124 consumed in its loop order
+    (results_linear_system.py:21-23, 209-233) -- for 10 loss rates x 4 runs x 250 steps, N = 20: device-resident loop
+    against the host loop."""
+    mpc, w = common.make_mpc("cartpole", 20, True, create=True)
+    p_loss = np.arange(10) / 10.0
+    n_mc, T = 4, 250
+    pl, th, ga, wd = montecarlo.draw_realisations_reference_order(p_loss, n_mc, T, w["w_bound"])
+    ref = np.full(T, 0.5)
+    dev = mpc.run_closed_loop(pl, ref, th, ga, wd)
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    host = montecarlo.run_remote_tube_mpc(mpc.determine_packets, w["A"], w["B"], K, Kp, 20, mpc._Z, pl, ref, th, ga, wd)
+    assert np.all(dev["not_optimal"] == 0) and np.all(dev["tube_violations"] == 0)
+    assert np.array_equal(dev["tube_violations"], host["tube_violations"])
+    np.testing.assert_allclose(dev["tracking_error"], host["tracking_error"], atol=1e-10, rtol=0)
+    np.testing.assert_allclose(dev["x_final"], host["x_final"], atol=1e-8, rtol=0)
+    assert dev["consistent_estimate_error"] < 1e-9                                  # Proposition 1 of the paper
+    # p_loss = 0 never drops a packet (strict <, :218): every loss-free run of the replay tracks identically up to the disturbance
+    assert np.ptp(dev["tracking_error"][:n_mc]) < 1e-2

@@ -17,13 +17,13 @@ S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
 def test_library_exports_every_declared_symbol(hip_lib):
     hdr = open(os.path.join(common.ROOT, "include", "tmpc.h")).read()
     declared = set(re.findall(r"\b(tmpc_[a-z_]+)\s*\(", hdr))
-    assert {"tmpc_create", "tmpc_destroy", "tmpc_solve_batch", "tmpc_solve_batch_device", "tmpc_synchronize", "tmpc_set_stream_min_batch",
+    assert {"tmpc_create", "tmpc_destroy", "tmpc_solve_batch", "tmpc_solve_batch_device", "tmpc_synchronize",
             "tmpc_last_kernel_ms", "tmpc_kernel_ms_total", "tmpc_get_dims", "tmpc_get_condensed", "tmpc_last_error",
             "tmpc_abi_version", "tmpc_set_kernel_path", "tmpc_get_kernel_path"} <= declared
     L = hip_lib.lib()
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/tmpc.h but not exported"
-    assert L.tmpc_abi_version() == 3
+    assert L.tmpc_abi_version() == 4
 
 
 def test_struct_layout_matches_header(hip_lib):

@@ -28,7 +28,7 @@ def cartpole(hip_lib, oracle_lib):
 
 def test_native_library_is_the_one_in_tree(hip_lib):
     assert os.path.samefile(hip_lib.LIB_PATH, os.path.join(common.PKG, "lib", "libtmpc_hip.so"))
-    assert hip_lib.lib().tmpc_abi_version() == 3
+    assert hip_lib.lib().tmpc_abi_version() == 4
 
 
 def test_golden_fixture_cartpole_N10(cartpole, hip_lib):
@@ -190,26 +190,6 @@ def test_reference_horizon_N20(hip_lib, oracle_lib):
     np.testing.assert_allclose(out["x_nom"], ref["x_nom"], atol=1e-8, rtol=0)
 
 
-def test_streaming_path_parity(cartpole, hip_lib):
-    """The opt-in streaming kernel (16 lanes per QP) + warm-started refinement gives the same
-    minimisers as the default one-wave-per-QP path and as the fixture."""
-    mpc, _, _ = cartpole
-    gold = np.load(os.path.join(common.GOLDEN, "cartpole_N10_oracle.npz"))
-    X = np.r_[S[:, :4], [[0.0, 0.0, 0.2, 0.0], [0.5, 0.0, 0.0, 0.0]]]      # + infeasible, + unconstrained
-    R = np.r_[S[:, 4:], [[0.5, 0, 0, 0.0], [0.5, 0, 0, 0.0]]]
-    base = mpc._solve(X, R)
-    hip_lib.set_stream_min_batch(mpc._handle, 1)
-    try:
-        out = mpc._solve(X, R)
-    finally:
-        hip_lib.set_stream_min_batch(mpc._handle, 0)
-    assert np.array_equal(out["status"], base["status"]) and list(out["status"][-2:]) == [2, 0]
-    np.testing.assert_allclose(out["u_nom"][:600], gold["u_nom"], atol=ATOL_U, rtol=0)
-    np.testing.assert_allclose(out["xu_ss"][:600], gold["xu_ss"], atol=ATOL_SS, rtol=0)
-    np.testing.assert_allclose(out["u_nom"][-1], base["u_nom"][-1], atol=1e-12)
-    assert np.all(np.isnan(out["u_nom"][-2]))
-
-
 @pytest.mark.parametrize("N", [5, 10])
 def test_config1_double_integrator_closed_loop(hip_lib, oracle_lib, N):
     """BASELINE config 1: Example_of_Tube_Tracking_MPC.py (free initial state, Rakovic sets,
@@ -265,10 +245,11 @@ def test_block_kernel_matches_fixture_and_wave_kernel(cartpole, hip_lib):
 @pytest.mark.parametrize("N", [10, 20])
 def test_extended_controller_both_problems(hip_lib, oracle_lib, N):
     """BASELINE config 3: ExtendedTubeTrackingMPC (TubeTrackingMPC.py:249-369), gamma_t per instance.  The
-    packet-received problem (Z (-) W on x_0, auxiliaries of :293 eliminated) goes through the block kernel."""
+    packet-received problem (Z (-) W on x_0 as the factored block, auxiliaries of :293 eliminated) has its own wave-kernel shape."""
     mpc, _ = common.make_mpc("cartpole", N, True, extended=True, create=True)
     nv1, nc1, _ = hip_lib.get_dims(mpc._handle, 1)
-    assert nv1 == N + 1 + 4 and nc1 > 900 and mpc.get_kernel_path(1) == "block"
+    assert nv1 == N + 1 + 4 and nc1 > 900 and mpc.get_kernel_path(1) == "wave"
+    assert hip_lib.kernel_name(mpc._handle, 1).startswith("tmpc::solve_kernel<%d,%d,0,4,7,0," % ((16, 1) if N == 10 else (28, 2)))
     SX = common.harvest_states("cartpole", N, True, [[0.5], [-0.4, 0.3], [0.2, -0.5, 0.1]], 40, seed=4, disturb=True, extended=True)
     gam = np.random.default_rng(1).integers(0, 2, len(SX)).astype(np.uint8)
     ref = Oracle(mpc._problem_dict()).solve(SX[:, :4], SX[:, 4:], gam)
