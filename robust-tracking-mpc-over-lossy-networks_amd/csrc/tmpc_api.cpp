@@ -143,7 +143,8 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const int NVP = v.shape.nvp, DP = v.shape.dp, DS = v.shape.ds, KCP = v.shape.kcp, CP = v.shape.cp, CS = v.shape.cs;
     const int NDP = (DP + DS) * 64, NCCP = (CP + CS) * 64, RS = 2 * DP + DS + 2 * CP + CS;
     const int kc = use_fact ? c.kc : 0;
-    std::vector<double> Gt(static_cast<size_t>(NVP) * NDP + 1, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
+    const int LDG = 16 * ((NVP + 1 + 15) / 16) + 1;        // Shape::LDG of tmpc_kernels.hip
+    std::vector<double> Gt(static_cast<size_t>(NDP) * LDG + 1, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
         Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), g0p(static_cast<size_t>(RS) * 64, 1.0), Esp(static_cast<size_t>(RS) * 64 * nx, 0.0);
     std::vector<uint32_t> vmask(64, 0u);
     std::vector<int32_t> row_of(static_cast<size_t>(RS) * 64, -1);
@@ -155,7 +156,7 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         row_of[sl] = row;
     };
     auto put_dense = [&](int fslot, int lane, int row) {
-        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(j) * NDP + fslot * 64 + lane] = c.Gs(row, j);
+        for (int j = 0; j < c.nv; ++j) Gt[static_cast<size_t>(fslot * 64 + lane) * LDG + j] = c.Gs(row, j);
     };
     auto put_fact = [&](int fslot, int lane, int row) {
         for (int a = 0; a < kc; ++a) Hct[static_cast<size_t>(a) * NCCP + fslot * 64 + lane] = c.Hc(row - c.fb0, a);
@@ -189,6 +190,11 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     int rc;
     if ((rc = upload_common(h, v, p, d, NVP))) return rc;
     d.nd = use_fact ? c.nd : c.nc; d.ncc = use_fact ? c.ncc : 0; d.kc = kc;
+    {
+        // k-steps (4 functionals each) of the MFMA pass over the dense functionals: up to the last one in use
+        const int last = dsing.empty() ? static_cast<int>(dpair.size()) : DP * 64 + static_cast<int>(dsing.size());
+        d.nks = (last + 3) / 4;
+    }
     if ((rc = upload(h, v, Gt.data(), Gt.size(), &d.Gt))) return rc;
     if ((rc = upload(h, v, Hct.data(), Hct.size(), &d.Hct))) return rc;
     if ((rc = upload(h, v, Psi.data(), Psi.size(), &d.Psi))) return rc;
@@ -231,7 +237,7 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     }
     int rc;
     if ((rc = upload_common(h, v, p, v.db, NVP))) return rc;
-    v.db.nd = c.nc; v.db.ncc = 0; v.db.kc = 0;
+    v.db.nd = c.nc; v.db.ncc = 0; v.db.kc = 0; v.db.nks = 0;
     v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = nullptr;
     v.db.vmask = nullptr; v.db.row_of = nullptr;
     v.bq.ncp = ncp;

@@ -22,10 +22,11 @@ struct DeviceQP {
     int nx, nu, N;
     int nv, nc, npar, nth;
     int nd, ncc, kc;      // dense rows, factored rows (nc = nd + ncc), factor width
+    int nks;              // k-steps of the MFMA pass over the dense functionals (4 functionals each)
     int off_theta, off_x0, off_aux;
     int max_iter, always_infeasible;
     double tol;
-    const double *Gt;     // [NVP][(DP+DS)*64]   dense functionals (paired slots first), scaled, transposed, zero padded
+    const double *Gt;     // [(DP+DS)*64][LDG]   dense functionals (paired slots first), scaled, row-major, zero padded; LDG = 16 ceil((NVP+1)/16) + 1
     const double *Hct;    // [KCP][(CP+CS)*64]   factored functionals' left factor, transposed, zero padded
     const double *Psi;    // [KCP][NVP]          factored rows' right factor
     const double *Hs;     // [NVP][NVP]          scaled Hessian, identity on the padding

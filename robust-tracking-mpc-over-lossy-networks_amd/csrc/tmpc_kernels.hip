@@ -53,6 +53,9 @@ using wv::readlane_d;
 using wv::rows_backsub_lane;
 using wv::rows_factor;
 using wv::rows_forward;
+using wv::vmax;
+using wv::vmax_abs;
+using wv::vmin;
 using wv::OpMax;
 using wv::OpMin;
 using wv::OpSum;
@@ -149,6 +152,12 @@ struct Shape {
     static constexpr int RS = 2 * DP_ + DS_ + 2 * CP_ + CS_;      // row sides per lane
     static constexpr int NT = NV_ * (NV_ + 1) / 2, KT = KC_ * (KC_ + 1) / 2;
     static constexpr int WCAP = NV_ <= 24 ? 24 : WS_CAP;          // max rows in the refinement's working set
+    // dense functionals, row-major in LDS: [FD * 64][LDG]; 16-column blocks of the MFMA tiling cover the NV columns of G
+    // plus one more row of the product (row NV of A carries t: see sweep_a_dense); the odd stride keeps both the
+    // lane-per-row reads of the sweeps and the 4 x 16 operand reads of the MFMA loop conflict free
+    static constexpr int NB = (NV_ + 1 + 15) / 16;
+    static constexpr int LDG = 16 * NB + 1;
+    static constexpr int NTL = NB * (NB + 1) / 2;                 // 16 x 16 tiles of the lower triangle
     // first row side and number of sides of dense functional slot kd / factored functional slot kc
     static constexpr int dbase(int kd) { return kd < DP_ ? 2 * kd : 2 * DP_ + (kd - DP_); }
     static constexpr int dsides(int kd) { return kd < DP_ ? 2 : 1; }
@@ -175,12 +184,13 @@ struct WaveLds {
     static constexpr int POL = 2 * SH::NV * SH::WCAP + 4 * SH::WCAP;                            // G_W, T, y, dy, W(idx)
     static constexpr int MFAC = SH::NV * (SH::NV + 1);                                  // factor of the normal matrix between the two solves (row i at i (NV + 1), then 1 / d_i)
     static constexpr int BIG = RED + MFAC > POL ? RED + MFAC : POL;                     // tile + factor (interior point) and the refinement's workspace are never live together
-    static constexpr int SUMS = SH::NT + 2 * SH::NV + 8;                                // dense totals of a sweep
+    static constexpr int SUMS = 2 * SH::NV + 8;                                         // two NV-vectors of G' products
+    static constexpr int DTW = 2 * SH::NDP;                                             // (D, t) per dense functional for the MFMA pass
     static constexpr int CSUMS = SH::KT + 2 * SH::KC + 8;                               // factored-block totals
     static constexpr int PMAT = SH::KCA * SH::NV;                                       // W * Psi
     static constexpr int HROW = SH::RS * WAVE;                                          // right-hand side h, [side][lane]
     static constexpr int VEC = 9 * SH::NV + 32;                                         // q, z, cost gradient, x_k, ref, scratch, dz_aff, dz, Psi-coordinates
-    static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC;
+    static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC + DTW;
 };
 
 // out = Psi vec for vectors kept in LDS: lane a < KC forms entry a (broadcast reads of vec)
@@ -198,11 +208,11 @@ __device__ __forceinline__ void coords_lds(const double *Psi, const double *vec,
 // g . v for this lane's dense functional of slot KD / factored functional of slot KCS; v (and c = Psi v) in LDS
 template <class SH, int KD>
 __device__ __forceinline__ double dense_dot(const double *Gt, const double *v, int lane) {
-    const int r = lane + KD * WAVE;
+    const double *g = Gt + (lane + KD * WAVE) * SH::LDG;
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-    for (int j = 0; j + 1 < SH::NV; j += 2) { t0 += Gt[j * SH::NDP + r] * v[j]; t1 += Gt[(j + 1) * SH::NDP + r] * v[j + 1]; }
-    if (SH::NV & 1) t0 += Gt[(SH::NV - 1) * SH::NDP + r] * v[SH::NV - 1];
+    for (int j = 0; j + 1 < SH::NV; j += 2) { t0 += g[j] * v[j]; t1 += g[j + 1] * v[j + 1]; }
+    if (SH::NV & 1) t0 += g[SH::NV - 1] * v[SH::NV - 1];
     return t0 + t1;
 }
 template <class SH, int KCS>
@@ -214,76 +224,78 @@ __device__ __forceinline__ double fact_dot(const double *Hct, const double *c, i
     return t;
 }
 
-// ---- sweep A, dense functionals, columns [J0, J1) of the lower triangle of G'DG.  The FIRST pass also forms 1/s and the
-// weights of both sides, the gap, |r_p|_inf and G'(d.r_p).
-template <class SH, int J0, int J1, bool FIRST>
-__device__ __forceinline__ void sweep_a_dense(const double *Gt, const double (&s)[SH::RS], const double (&lam)[SH::RS],
-                                              const double *rpw, double (&rs)[SH::RS],
-                                              double (&dd)[SH::FD > 0 ? SH::FD : 1], double &gap_l, double &rpn_l, double *red,
-                                              double *sums, int lane) {
-    constexpr int NV = SH::NV, NDP = SH::NDP, NT = SH::NT;
-    constexpr int TRI = col_off<NV>(J1) - col_off<NV>(J0);
-    constexpr int CNT = TRI + (FIRST ? NV : 0);
-    constexpr int I0 = FIRST ? 0 : J0;        // first column this pass has to load
-    double acc[CNT];
-#pragma unroll
-    for (int i = 0; i < CNT; ++i) acc[i] = 0.0;
+// ---- sweep A, dense functionals: 1/s and the weights of both sides, the gap, |r_p|_inf; then
+//          [ G'DG      ]     [ (D.G)' ]
+//          [ (G't)'    ]  =  [  t'    ]  G          with D = sum of the sides' lambda / s, t = sum of +-(lambda / s) r_p
+// on the FP64 matrix cores (v_mfma_f64_16x16x4_f64): the sum over the functionals happens inside the instruction -- no
+// per-lane accumulators (NV (NV + 1) / 2 of them in a vector-ALU formulation) and no cross-lane reduction.  A operand
+// (16 x 4 per k-step): lane l holds column k = l / 16 of row i = l % 16, i.e. D_f g_f[16 I + i] of functional f = 4 ks + k
+// (row NV: t_f); B operand (4 x 16): g_f[16 J + j], j = l % 16 -- the same LDS value, read once.  C/D: lane l holds
+// rows (l / 16) + 4 reg, column l % 16 of a tile.  The tiles go to LDS as full rows of M (mt, stride NV + 1) and row NV
+// as the vector G't (gdr).
+typedef double v4d __attribute__((ext_vector_type(4)));
+template <class SH>
+__device__ __forceinline__ void sweep_a_dense(const double *Gt, int nks, const double (&s)[SH::RS], const double (&lam)[SH::RS],
+                                              const double *rpw, double (&rs)[SH::RS], double &gap_l, double &rpn_l,
+                                              double *dtw, double *mt, double *gdr, int lane) {
+    constexpr int NV = SH::NV, NB = SH::NB, LDG = SH::LDG, IT = NV / 16, CT = NV % 16;
     static_for<SH::FD>([&](auto kd_) {
         constexpr int kd = decltype(kd_)::value;
-        const int r = lane + kd * WAVE;
-        double g[NV];
+        double D = 0.0, t = 0.0;
 #pragma unroll
-        for (int j = I0; j < NV; ++j) g[j] = Gt[j * NDP + r];
-        if constexpr (FIRST) {
-            double D = 0.0, t = 0.0;
-#pragma unroll
-            for (int sd = 0; sd < SH::dsides(kd); ++sd) {
-                constexpr int base = SH::dbase(kd);
-                const int i = base + sd;
-                const double rsi = fast_rcp(s[i]);
-                rs[i] = rsi;
-                const double d = lam[i] * rsi;
-                const double rpi = rpw[i * WAVE + lane];
-                gap_l = fma(s[i], lam[i], gap_l);
-                rpn_l = fmax(rpn_l, fabs(rpi));
-                D += d;
-                t = sd ? fma(-d, rpi, t) : fma(d, rpi, t);
-            }
-            dd[kd] = D;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) acc[TRI + i] = fma(g[i], t, acc[TRI + i]);
+        for (int sd = 0; sd < SH::dsides(kd); ++sd) {
+            constexpr int base = SH::dbase(kd);
+            const int i = base + sd;
+            const double rsi = fast_rcp(s[i]);
+            rs[i] = rsi;
+            const double d = lam[i] * rsi;
+            const double rpi = rpw[i * WAVE + lane];
+            gap_l = fma(s[i], lam[i], gap_l);
+            rpn_l = vmax_abs(rpn_l, rpi);
+            D += d;
+            t = sd ? fma(-d, rpi, t) : fma(d, rpi, t);
         }
-        const double D = dd[kd];
-#pragma unroll
-        for (int j = J0; j < J1; ++j) {
-            const double dg = D * g[j];
-#pragma unroll
-            for (int i = j; i < NV; ++i) acc[col_off<NV>(j) - col_off<NV>(J0) + i - j] = fma(dg, g[i], acc[col_off<NV>(j) - col_off<NV>(J0) + i - j]);
-        }
-        row_fence();
+        dtw[2 * (kd * WAVE + lane)] = D;
+        dtw[2 * (kd * WAVE + lane) + 1] = t;
     });
-    if constexpr (FIRST) {
-        double tri[TRI > 0 ? TRI : 1], vecs[NV];
+    wave_lds_fence();
+    const int c = lane & 15, kq = lane >> 4;
+    const double tmask = (c == CT) ? 1.0 : 0.0;
+    v4d acc[SH::NTL];
 #pragma unroll
-        for (int i = 0; i < TRI; ++i) tri[i] = acc[i];
+    for (int q = 0; q < SH::NTL; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (int ks = 0; ks < nks; ++ks) {
+        const int f = 4 * ks + kq;
+        const double Dk = dtw[2 * f], tk = dtw[2 * f + 1];
+        double g[NB], a[NB];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) vecs[i] = acc[TRI + i];
-        if constexpr (TRI > 0) wave_reduce_to_lds<TRI, SH::RR>(tri, red, sums + col_off<NV>(J0), lane);
-        wave_reduce_to_lds<NV, SH::RR>(vecs, red, sums + NT, lane);
-    } else {
-        wave_reduce_to_lds<CNT, SH::RR>(acc, red, sums + col_off<NV>(J0), lane);
+        for (int blk = 0; blk < NB; ++blk) {
+            g[blk] = Gt[f * LDG + 16 * blk + c];
+            a[blk] = Dk * g[blk];
+        }
+        a[IT] = fma(tmask, tk, a[IT]);              // (column NV of G is zero: row NV of the product is G't)
+#pragma unroll
+        for (int I = 0; I < NB; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J)
+                acc[I * (I + 1) / 2 + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], g[J], acc[I * (I + 1) / 2 + J], 0, 0, 0);
     }
-}
-template <class SH, int BI>
-__device__ __forceinline__ void sweep_a_dense_all(const double *Gt, const double (&s)[SH::RS], const double (&lam)[SH::RS],
-                                                  const double *rpw, double (&rs)[SH::RS],
-                                                  double (&dd)[SH::FD > 0 ? SH::FD : 1], double &gap_l, double &rpn_l, double *red,
-                                                  double *sums, int lane) {
-    using BL = Blocks<SH::NV>;
-    if constexpr (BI < BL::n) {
-        sweep_a_dense<SH, BL::b[BI], BL::b[BI + 1], BI == 0>(Gt, s, lam, rpw, rs, dd, gap_l, rpn_l, red, sums, lane);
-        sweep_a_dense_all<SH, BI + 1>(Gt, s, lam, rpw, rs, dd, gap_l, rpn_l, red, sums, lane);
-    }
+#pragma unroll
+    for (int I = 0; I < NB; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * I + kq + 4 * reg, col = 16 * J + c;
+                const double v = acc[I * (I + 1) / 2 + J][reg];
+                if (row < NV && col < NV) {
+                    mt[row * (NV + 1) + col] = v;
+                    if (I != J) mt[col * (NV + 1) + row] = v;
+                }
+                if (I == IT && row == NV && col < NV) gdr[col] = v;
+            }
+    wave_lds_fence();
 }
 
 // The FACTORED functionals: KC-wide left factor, so W = Hc' D Hc has only KT entries; one pass.
@@ -292,9 +304,7 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
                                                  const double *rpw, double (&rs)[SH::RS], double &gap_l, double &rpn_l,
                                                  double *red, double *csums, int lane) {
     constexpr int KC = SH::KC, KT = SH::KT, NCCP = SH::NCCP;
-    double acc[KT + KC];
-#pragma unroll
-    for (int i = 0; i < KT + KC; ++i) acc[i] = 0.0;
+    double acc[KT + KC];       // initialised by the first slot's products
     static_for<SH::FC>([&](auto kc_) {
         constexpr int kc = decltype(kc_)::value;
         const int r = lane + kc * WAVE;
@@ -311,7 +321,7 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
             const double d = lam[i] * rsi;
             const double rpi = rpw[i * WAVE + lane];
             gap_l = fma(s[i], lam[i], gap_l);
-            rpn_l = fmax(rpn_l, fabs(rpi));
+            rpn_l = vmax_abs(rpn_l, rpi);
             D += d;
             t = sd ? fma(-d, rpi, t) : fma(d, rpi, t);
         }
@@ -319,10 +329,9 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
         for (int a = 0; a < KC; ++a) {
             const double dg = D * hc[a];
 #pragma unroll
-            for (int b2 = a; b2 < KC; ++b2) acc[col_off<KC>(a) + b2 - a] = fma(dg, hc[b2], acc[col_off<KC>(a) + b2 - a]);
-            acc[KT + a] = fma(hc[a], t, acc[KT + a]);
+            for (int b2 = a; b2 < KC; ++b2) acc[col_off<KC>(a) + b2 - a] = kc == 0 ? dg * hc[b2] : fma(dg, hc[b2], acc[col_off<KC>(a) + b2 - a]);
+            acc[KT + a] = kc == 0 ? hc[a] * t : fma(hc[a], t, acc[KT + a]);
         }
-        row_fence();
     });
     wave_reduce_to_lds<KT + KC, SH::RR>(acc, red, csums, lane);
 }
@@ -336,10 +345,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const int32_t *__restrict__ ws_in, int32_t *__restrict__ ws_out) {
     using SH = Shape<NV, DP, DS, KC, CP, CS, (WPB == 8 ? 12 : 16)>;
     using WL = WaveLds<SH>;
-    constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, NT = SH::NT, KT = SH::KT, WCAP = SH::WCAP;
+    constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, KT = SH::KT, WCAP = SH::WCAP, LDG = SH::LDG;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *Gt = smem;                         // [NV][NDP]
-    double *Hct = Gt + NV * NDP;               // [KC][NCCP]
+    double *Gt = smem;                         // [NDP][LDG]  dense functionals, row-major (odd stride)
+    double *Hct = Gt + NDP * LDG;              // [KC][NCCP]
     double *Psi = Hct + KC * NCCP;             // [KC][NV]
     double *Hs = Psi + KC * NV;                // [NV][NV]
     double *Hinv = Hs + NV * NV;               // [NV][NV]
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nc = qp.nc;
 
     // ---- stage the shared model once per workgroup (coalesced, L2-resident source)
-    for (int i = tid; i < NV * NDP; i += blockDim.x) Gt[i] = qp.Gt[i];
+    for (int i = tid; i < NDP * LDG; i += blockDim.x) Gt[i] = qp.Gt[i];
     for (int i = tid; i < KC * NCCP; i += blockDim.x) Hct[i] = qp.Hct[i];
     for (int i = tid; i < KC * NV; i += blockDim.x) Psi[i] = qp.Psi[i];
     for (int i = tid; i < NV * NV; i += blockDim.x) { Hs[i] = qp.Hs[i]; Hinv[i] = qp.Hinv[i]; }
@@ -364,7 +373,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *Pm = csums + WL::CSUMS;               // [KC][NV] W * Psi
     double *hw = Pm + WL::PMAT;                   // h, [side][lane]
     double *vec = hw + WL::HROW;
-    double *Mf = red + WL::RED;       // [NV][NV + 1]  (behind the transposition tile, inside the refinement's idle workspace)
+    double *dtw = vec + WL::VEC;      // [NDP][2] (D, t) of the dense functionals (MFMA pass of sweep A)
+    double *Mf = red + WL::RED;       // [NV][NV + 1]  normal matrix, then its factor (behind the transposition tile, inside the refinement's idle workspace)
     double *qv = vec;                 // [NV] linear term
     double *zv = vec + NV;            // [NV] current z (wave-uniform copy)
     double *cgv = vec + 2 * NV;       // [NV] cost gradient
@@ -459,7 +469,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 for (int sd = 0; sd < SH::dsides(kd); ++sd) {
                     const int i = SH::dbase(kd) + sd;
                     sl[i] = hw[i * WAVE + lane] - (sd ? -gz : gz);
-                    if (valid(i)) smin = fmin(smin, sl[i]);
+                    if (valid(i)) smin = vmin(smin, sl[i]);
                 }
             });
             static_for<FC>([&](auto kc_) {
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 for (int sd = 0; sd < SH::csides(kc); ++sd) {
                     const int i = SH::cbase(kc) + sd;
                     sl[i] = hw[i * WAVE + lane] - (sd ? -gz : gz);
-                    if (valid(i)) smin = fmin(smin, sl[i]);
+                    if (valid(i)) smin = vmin(smin, sl[i]);
                 }
             });
             return smin;
@@ -536,13 +546,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 }
                 for (int it = 0; it < qp.max_iter; ++it) {
                     it_done = it;
+                    STAMP(9);
                     TMPC_REFRESH();
                     // ---- sweep A: 1/s, weights, gap, |r_p|, G'DG (dense functionals by column blocks, factored ones as W), G'(d.r_p)
                     double gap_l = 0.0, rpn_l = 0.0;
-                    {
-                        double dd[FD > 0 ? FD : 1];
-                        if constexpr (FD > 0) sweep_a_dense_all<SH, 0>(Gt, s, lam, rpw, rs, dd, gap_l, rpn_l, red, sums, lane);
-                    }
+                    if constexpr (FD > 0) sweep_a_dense<SH>(Gt, qp.nks, s, lam, rpw, rs, gap_l, rpn_l, dtw, Mf, sums, lane);
                     if constexpr (KC > 0) {
                         TMPC_REFRESH();
                         sweep_a_factored<SH>(Hct, s, lam, rpw, rs, gap_l, rpn_l, red, csums, lane);
@@ -559,17 +567,17 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         }
                         double v1 = 0.0;
                         if (lane < NV) {
-                            v1 = (FD > 0) ? sums[NT + lane] : 0.0;
+                            v1 = (FD > 0) ? sums[lane] : 0.0;
 #pragma unroll
                             for (int a = 0; a < KC; ++a) v1 += Psi[a * NV + lane] * csums[KT + a];
                         }
                         wave_lds_fence();
-                        if (lane < NV) sums[NT + lane] = v1;
+                        if (lane < NV) sums[lane] = v1;
                         wave_lds_fence();
                     }
                     double lmax = 0.0;
 #pragma unroll
-                    for (int i = 0; i < RS; ++i) lmax = fmax(lmax, lam[i]);
+                    for (int i = 0; i < RS; ++i) lmax = vmax(lmax, lam[i]);
                     const double rpn = wave_max(rpn_l);
                     lmax = wave_max(lmax);
                     const double gap = wave_sum(gap_l);
@@ -607,10 +615,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 double dl2 = lam[SH::dbase(kd)];
                                 if constexpr (SH::dsides(kd) == 2) dl2 -= lam[SH::dbase(kd) + 1];
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) accl[j] = fma(Gt[j * NDP + r], dl2, accl[j]);
+                                for (int j = 0; j < NV; ++j) accl[j] = fma(Gt[r * LDG + j], dl2, accl[j]);
                                 row_fence();
                             });
-                            wave_reduce_to_lds<NV, SH::RR>(accl, red, sums + NT + NV, lane);
+                            wave_reduce_to_lds<NV, SH::RR>(accl, red, sums + NV, lane);
                         }
                         if constexpr (KC > 0) {
                             double accl[KC];
@@ -627,18 +635,18 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             wave_reduce_to_lds<KC, SH::RR>(accl, red, csums + KT + KC, lane);
                             double gl = 0.0;
                             if (lane < NV) {
-                                gl = (FD > 0) ? sums[NT + NV + lane] : 0.0;
+                                gl = (FD > 0) ? sums[NV + lane] : 0.0;
 #pragma unroll
                                 for (int a = 0; a < KC; ++a) gl += Psi[a * NV + lane] * csums[KT + KC + a];
                             }
                             wave_lds_fence();
-                            if (lane < NV) sums[NT + NV + lane] = gl;
+                            if (lane < NV) sums[NV + lane] = gl;
                             wave_lds_fence();
                         }
                         double rdn = 0.0, gn = 0.0;
 #pragma unroll
                         for (int j = 0; j < NV; ++j) {
-                            const double glj = sums[NT + NV + j];
+                            const double glj = sums[NV + j];
                             rdn = fmax(rdn, fabs(cgv[j] + glj));
                             gn = fmax(gn, fabs(glj));
                         }
@@ -668,25 +676,32 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         double shift = 0.0;
                         bool spd = false;
                         for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
-                            // row li of M is formed in a ROLLED loop into LDS (the transposition tile is idle here) and read back:
-                            // unrolled, the 2 + KC loads per entry are all hoisted to the top of the block and blow the live set
-                            double *mt = red + li * (NV + 1);
-#pragma unroll 1
-                            for (int j = 0; j < NV; ++j) {
-                                const int lo = li < j ? li : j, hi2 = li < j ? j : li;
-                                double v = Hs[li * NV + j] + (li == j ? shift : 0.0);
-                                if constexpr (FD > 0) v += sums[lo * NV - lo * (lo - 1) / 2 + hi2 - lo];
-                                if constexpr (KC > 0) {
+                            // M = Hs + G'DG: the dense part sits in the tile (rows of stride NV + 1, written by the MFMA pass), the
+                            // factored part is Psi' (W Psi); the NV^2 entries are spread over the 64 lanes, then lane i reads row i
+                            double *mt = Mf + li * (NV + 1);        // (not the transposition tile: the dual-residual pass may have used it)
+                            if (attempt == 0) {
 #pragma unroll
-                                    for (int a = 0; a < KC; ++a) v += Psi[a * NV + li] * Pm[a * NV + j];
+                                for (int q = 0; q * WAVE < NV * NV; ++q) {
+                                    const int e = lane + q * WAVE;
+                                    if (e < NV * NV) {
+                                        const int i = e / NV, j = e - i * NV;
+                                        double v = Hs[e];
+                                        if constexpr (FD > 0) v += Mf[i * (NV + 1) + j];
+                                        if constexpr (KC > 0) {
+#pragma unroll
+                                            for (int a = 0; a < KC; ++a) v += Psi[a * NV + i] * Pm[a * NV + j];
+                                        }
+                                        Mf[i * (NV + 1) + j] = v;
+                                    }
                                 }
-                                if (lane < NV) mt[j] = v;
+                            } else if (lane < NV) {
+                                mt[li] += shift;
                             }
                             wave_lds_fence();
 #pragma unroll
                             for (int j = 0; j < NV; ++j) mrow[j] = (lane < NV) ? mt[j] : 0.0;
                             wave_lds_fence();
-                            rhs_i = (lane < NV) ? -cgv[li] - sums[NT + li] : 0.0;
+                            rhs_i = (lane < NV) ? -cgv[li] - sums[li] : 0.0;
                             double bb = rhs_i;
                             mdinv = 1.0;
                             spd = rows_factor<NV>(mrow, bb, mdinv, lane);
@@ -725,7 +740,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const double q = dsa * rs[i];
                             const double u = 1.0 + q;
                             const double dla = -lam[i] * u;
-                            rho_aff = fmax(rho_aff, fmax(-q, u));
+                            rho_aff = vmax(rho_aff, vmax(-q, u));
                             const double w = dsa * dla;
                             sb1 = fma(s[i], dla, fma(lam[i], dsa, sb1));
                             sb2 += w;
@@ -735,15 +750,13 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         };
                         if constexpr (FD > 0) {
                             double accb[2 * NV];
-#pragma unroll
-                            for (int i = 0; i < 2 * NV; ++i) accb[i] = 0.0;
                             static_for<FD>([&](auto kd_) {
                                 constexpr int kd = decltype(kd_)::value;
                                 const int r = lane + kd * WAVE;
                                 double g[NV];
                                 double gd0 = 0.0, gd1 = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) g[j] = Gt[j * NDP + r];
+                                for (int j = 0; j < NV; ++j) g[j] = Gt[r * LDG + j];
 #pragma unroll
                                 for (int j = 0; j + 1 < NV; j += 2) { gd0 = fma(g[j], dzav[j], gd0); gd1 = fma(g[j + 1], dzav[j + 1], gd1); }
                                 if (NV & 1) gd0 = fma(g[NV - 1], dzav[NV - 1], gd0);
@@ -751,15 +764,16 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #pragma unroll
                                 for (int sd = 0; sd < SH::dsides(kd); ++sd) side_stats(SH::dbase(kd) + sd, sd == 1, gd0 + gd1, c1, c2);
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) { accb[j] = fma(g[j], c1, accb[j]); accb[NV + j] = fma(g[j], c2, accb[NV + j]); }
+                                for (int j = 0; j < NV; ++j) {
+                                    accb[j] = kd == 0 ? g[j] * c1 : fma(g[j], c1, accb[j]);
+                                    accb[NV + j] = kd == 0 ? g[j] * c2 : fma(g[j], c2, accb[NV + j]);
+                                }
                                 row_fence();
                             });
-                            wave_reduce_to_lds<2 * NV, SH::RR>(accb, red, sums + NT, lane);   // overwrites G'(d.rp), G'lam (consumed)
+                            wave_reduce_to_lds<2 * NV, SH::RR>(accb, red, sums, lane);   // overwrites G'(d.rp), G'lam (consumed)
                         }
                         if constexpr (KC > 0) {
                             double accc[2 * KC];
-#pragma unroll
-                            for (int i = 0; i < 2 * KC; ++i) accc[i] = 0.0;
                             static_for<FC>([&](auto kc_) {
                                 constexpr int kc = decltype(kc_)::value;
                                 const int r = lane + kc * WAVE;
@@ -771,8 +785,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #pragma unroll
                                 for (int sd = 0; sd < SH::csides(kc); ++sd) side_stats(SH::cbase(kc) + sd, sd == 1, gdz, c1, c2);
 #pragma unroll
-                                for (int a = 0; a < KC; ++a) { accc[a] = fma(hc[a], c1, accc[a]); accc[KC + a] = fma(hc[a], c2, accc[KC + a]); }
-                                row_fence();
+                                for (int a = 0; a < KC; ++a) {
+                                    accc[a] = kc == 0 ? hc[a] * c1 : fma(hc[a], c1, accc[a]);
+                                    accc[KC + a] = kc == 0 ? hc[a] * c2 : fma(hc[a], c2, accc[KC + a]);
+                                }
                             });
                             wave_reduce_to_lds<2 * KC, SH::RR>(accc, red, csums + KT, lane);
                         }
@@ -780,7 +796,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         sb1 = wave_sum(sb1);
                         sb2 = wave_sum(sb2);
                         if (lane < NV) {
-                            if constexpr (FD > 0) { v2 = sums[NT + lane]; v3 = sums[NT + NV + lane]; }
+                            if constexpr (FD > 0) { v2 = sums[lane]; v3 = sums[NV + lane]; }
                             if constexpr (KC > 0) {
 #pragma unroll
                                 for (int a = 0; a < KC; ++a) { v2 += Psi[a * NV + lane] * csums[KT + a]; v3 += Psi[a * NV + lane] * csums[KT + KC + a]; }
@@ -821,7 +837,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const double t1 = fma(lam[i], dsk, wv_[i] - smu);
                             const double dlk = valid(i) ? fma(-t1, rs[i], -lam[i]) : 0.0;
                             const double rl = valid(i) ? rcp1(lam[i]) : 0.0;
-                            rho = fmax(rho, fmax(-dsk * rs[i], -dlk * rl));
+                            rho = vmax(rho, vmax(-dsk * rs[i], -dlk * rl));
                             rs[i] = dsk;
                             wv_[i] = dlk;
                         };
@@ -837,7 +853,6 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const double gdz = fact_dot<SH, kc>(Hct, cdzv, lane);
 #pragma unroll
                             for (int sd = 0; sd < SH::csides(kc); ++sd) side_step(SH::cbase(kc) + sd, sd == 1, gdz);
-                            row_fence();
                         });
                     }
                     rho = wave_max(rho);
@@ -929,7 +944,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const int r = fs * WAVE + (gid & 63);
                             double v = 0.0;
                             if (dense) {
-                                if constexpr (FD > 0) v = Gt[j * NDP + r];
+                                if constexpr (FD > 0) v = Gt[r * LDG + j];
                             } else {
                                 if constexpr (KC > 0) {
 #pragma unroll
@@ -1155,7 +1170,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 
 template <class SH>
 constexpr size_t kernel_lds_bytes(int wpb) {
-    return sizeof(double) * (static_cast<size_t>(SH::NV) * SH::NDP + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
+    return sizeof(double) * (static_cast<size_t>(SH::LDG) * SH::NDP + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
                              static_cast<size_t>(wpb) * WaveLds<SH>::TOTAL);
 }
 // Waves per workgroup = waves per CU (one persistent workgroup per CU).  Eight (two per SIMD: at most 256 registers each,

@@ -6,7 +6,7 @@ import numpy as np
 import common
 from LinearMPCOverNetworks import _native
 _native.LIB_PATH = os.path.join(common.PKG, "lib", "libtmpc_stamps.so")
-names = ["setup", "sweepA+reduce", "grad/conv", "factor+solve1", "sweepB+reduce", "solve2", "sweepD+update", "polish", "outputs"]
+names = ["setup", "sweepA+reduce", "grad/conv", "factor+solve1", "sweepB+reduce", "solve2", "sweepD+update", "polish", "outputs", "loop-top"]
 def run(name, N, fixed, X, R, B):
     mpc, w = common.make_mpc(name, N, fixed, create=True)
     h = mpc._handle
@@ -16,7 +16,7 @@ def run(name, N, fixed, X, R, B):
         o = mpc._solve(X[:B], R[:B], want_traj=False)
     buf = (C.c_longlong * 12)()
     L.tmpc_debug_stamps(h.ptr, 0, buf)
-    t = np.array(buf[:9], dtype=float)
+    t = np.array(buf[:10], dtype=float)
     it = max(int(o["iters"][0]), 1)
     print(f"{name} N={N} B={B}: instance 0 iters {it}, total {t.sum():.0f} ticks (100 MHz => {t.sum()/100:.1f} us), kernel {_native.last_kernel_ms(h)*1e3:.1f} us")
     for n_, v in zip(names, t):
