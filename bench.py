@@ -5,18 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W      (N > 1, one rank per GPU)
 
-Workload (BASELINE.json configs[1]): linearised cartpole n=4, m=1, horizon N=10, fixed
-initial state (results_linear_system.py:120), batch 4096 (x_k, ref) pairs PER GPU (weak
-scaling), the pairs drawn from the closed-loop transients in tests/golden (synthetic, seeded).
-One step = one tmpc_solve_batch_device call over the batch, inputs already in HBM.
+Workload (BASELINE.json configs[1]): linearised cartpole n=4, m=1, horizon N=10, fixed initial state
+(results_linear_system.py:120), p_loss = 0.3, batch 4096 (x_k, ref) pairs PER GPU (weak scaling).  The pairs are the
+estimates and references the remote controller is actually asked to solve: at start-up every rank builds the controller
+(offline sets through the batched LP kernel, 0.2 s) and runs 4096 / 32 seeded closed loops over the lossy network for 32 steps
+with its own device solver (workloads.harvest_closed_loop_states): 4096 DISTINCT states, synthetic and seeded.  One step =
+one tmpc_solve_batch_device call over the batch, inputs already in HBM (eight seeded random orders of the batch are resident,
+the steps go round them).
 
-Metric: QP solves per second (= MPC steps per second), whole job.  The same JSON line
-carries
-  roofline      FP64 flops of the interior-point iterations actually executed (iters per
-                instance come back from the device) over the average kernel duration from HIP
-                events on the solve stream, against the MI355X FP64 peak;
-  cpu_baseline  the CPU oracle (oracle/tmpc_oracle.c, OpenMP over the batch) timed on this
-                box's host cores on a bounded sample of the same workload.
+Metric: QP solves per second (= MPC steps per second), whole job.  The same JSON line carries
+  roofline      FP64 flops of the interior-point iterations actually executed (iters per instance come back from the
+                device; F_it of SURVEY.md 8(d)) over the average kernel duration from HIP events on the solve stream,
+                against the MI355X FP64 peak; kernel name from the library (tmpc_kernel_name);
+  cpu_baseline  the CPU oracle (oracle/tmpc_oracle.c, OpenMP over the batch) timed on this box's host cores on a
+                bounded sample of the same workload;
+  extras        closed loop on the device (cold and warm-started), BASELINE configs[2] (N = 20 extended controller,
+                batch 65536, gamma from a real closed loop) and configs[4] (n = 12, m = 4, N = 30, batch 16384), each with
+                its own roofline, and the offline LP stage.
+Nothing here reads tests/ : the controller set-up lives in the package (workloads.make_controller).
 """
 import argparse
 import json
@@ -27,7 +33,8 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "robust-tracking-mpc-over-lossy-networks_amd"))
+sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X FP64 vector = FP64 matrix peak (AMD datasheet)
 HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md
@@ -55,14 +62,81 @@ def host_cores():
     return cores
 
 
+def measured_traffic(kernel_name):
+    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
+    only reported when the profile was taken on the very kernel instantiation the library runs now."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+        return t.get("hbm_bytes_per_launch") if t.get("kernel") == kernel_name else None
+    except Exception:
+        return None
+
+
+class DeviceBatch:
+    """Inputs and outputs of one solve call, resident in HBM."""
+
+    def __init__(self, torch, dev, X, R, gamma, N, nu):
+        B, nx = X.shape
+        self.B = B
+        self.x = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+        self.r = torch.from_numpy(np.ascontiguousarray(R)).to(dev)
+        self.g = None if gamma is None else torch.from_numpy(np.ascontiguousarray(gamma.astype(np.uint8))).to(dev)
+        self.u = torch.empty((B, N, nu), dtype=torch.float64, device=dev)
+        self.x0 = torch.empty((B, nx), dtype=torch.float64, device=dev)
+        self.ss = torch.empty((B, nx + nu), dtype=torch.float64, device=dev)
+        self.st = torch.empty(B, dtype=torch.int32, device=dev)
+        self.it = torch.empty(B, dtype=torch.int32, device=dev)
+
+    def solve(self, native, h):
+        native.solve_batch_device(h, self.B, self.x.data_ptr(), self.r.data_ptr(), None if self.g is None else self.g.data_ptr(),
+                                  self.u.data_ptr(), self.x0.data_ptr(), self.ss.data_ptr(), None, self.st.data_ptr(), self.it.data_ptr())
+
+
+def timed_solves(native, torch, h, batch, steps, warmup):
+    """-> (wall seconds for `steps` calls, average kernel ms per call from HIP events on the solve stream)."""
+    for _ in range(warmup):
+        batch.solve(native, h)
+    native.synchronize(h)
+    torch.cuda.synchronize()
+    native.kernel_ms_total(h, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        batch.solve(native, h)
+    native.synchronize(h)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n = native.kernel_ms_total(h, reset=True)
+    return dt, ms / max(n, 1)
+
+
+def roofline_entry(native, h, batch, gamma, avg_ms):
+    """FP64 roofline of one call: sum over the instances of iters * F_it(nv, nc) of their variant."""
+    it = batch.it.cpu().numpy().astype(np.float64)
+    st = batch.st.cpu().numpy()
+    flops, kernels, dims = 0.0, [], []
+    for v in ([0] if gamma is None else sorted(set(gamma.tolist()))):
+        nv, nc, _ = native.get_dims(h, int(v))
+        m = np.ones(len(it), bool) if gamma is None else (gamma == v)
+        flops += float(it[m].sum()) * flops_per_iteration(nv, nc)
+        kernels.append(native.kernel_name(h, int(v)))
+        dims.append({"variant": int(v), "nv": nv, "nc": nc, "instances": int(m.sum()), "mean_ipm_iters": float(it[m].mean()) if m.any() else 0.0})
+    ach = flops / (avg_ms * 1e-3) / 1e12
+    return ({"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
+             "kernel": " + ".join(kernels), "avg_kernel_ms": avg_ms, "flops_per_launch": flops},
+            dims, float((st == 0).mean()), float((st == 2).mean()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=4096, help="QP instances per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop extra (profiling runs: keeps the kernel statistics to the timed steps)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the config-3 / config-5 / offline-LP extras")
+    ap.add_argument("--only", choices=["config3", "config5"], default=None,
+                    help="profiling runs: time ONLY this extra's solve calls (rocprofv3 kernel statistics then belong to it)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -75,8 +149,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    import common
-    from LinearMPCOverNetworks import _native
+    from LinearMPCOverNetworks import _native, montecarlo, workloads
 
     # TMPC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share the devices, the
     # statistics gather goes through host memory); the driver's runs use nccl (= RCCL), one rank per GPU
@@ -91,27 +164,65 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    mpc, w = common.make_mpc("cartpole", 10, True, create=True, device=dev_index)
+    def config3_extra():
+        """BASELINE configs[2]: N = 20, ExtendedTubeTrackingMPC, batch 65536; states and gamma from extended closed loops."""
+        mpc3, w3 = workloads.make_controller("cartpole", 20, True, extended=True, device=dev_index)
+        X3, R3, G3 = workloads.harvest_closed_loop_states(mpc3, w3, 512, 32, seed=300 + rank, extended=True)
+        reps = 65536 // len(X3)
+        X3, R3, G3 = np.tile(X3, (reps, 1)), np.tile(R3, (reps, 1)), np.tile(G3, reps)
+        p3 = np.random.default_rng(3000 + rank).permutation(len(X3))
+        X3, R3, G3 = X3[p3], R3[p3], G3[p3]
+        b3 = DeviceBatch(torch, dev, X3, R3, G3, 20, 1)
+        dt, ms = timed_solves(_native, torch, mpc3._handle, b3, 10, 2)
+        roof, dims, opt, inf = roofline_entry(_native, mpc3._handle, b3, G3, ms)
+        return {"value": len(X3) * 10 / dt, "unit": "solves/s", "batch": len(X3), "distinct_states": len(X3) // reps, "steps": 10,
+                "ms_per_step": dt / 10 * 1e3, "gamma1_fraction": float(G3.mean()), "optimal_fraction": opt, "infeasible_fraction": inf,
+                "variants": dims, "roofline": roof,
+                "note": "cartpole N=20, ExtendedTubeTrackingMPC (results_linear_system_with_extendedMPC.py), (x_hat, ref, gamma) from "
+                        "512 extended closed loops x 32 steps at p_loss 0.3, tiled to the batch; both problems in one call"}
+
+    def config5_extra():
+        """BASELINE configs[4]: synthetic n = 12, m = 4, N = 30, batch 16384 (block kernel, MFMA normal matrix)."""
+        mpc5, w5 = workloads.make_controller("synthetic", 30, True, device=dev_index)
+        rng = np.random.default_rng(50 + rank)
+        B5 = 16384
+        X5 = rng.uniform(-0.5, 0.5, (B5, 12)) * mpc5._Xc.b[:12]                # SURVEY.md 8(d): (x_k, ref) uniform in 0.5 Xc
+        R5 = np.zeros((B5, 12))
+        R5[:, 0] = rng.uniform(-2, 2, B5)
+        b5 = DeviceBatch(torch, dev, X5, R5, None, 30, 4)
+        dt, ms = timed_solves(_native, torch, mpc5._handle, b5, 3, 1)
+        roof, dims, opt, inf = roofline_entry(_native, mpc5._handle, b5, None, ms)
+        return {"value": B5 * 3 / dt, "unit": "solves/s", "batch": B5, "steps": 3, "ms_per_step": dt / 3 * 1e3,
+                "optimal_fraction": opt, "infeasible_fraction": inf, "variants": dims, "roofline": roof,
+                "note": "random stable (A, B), n=12, m=4, N=30, Darup sets, x_k uniform in 0.5 Xc (SURVEY.md 8d)"}
+
+    if args.only:
+        out = {"config3": config3_extra, "config5": config5_extra}[args.only]()
+        if rank == 0:
+            print(json.dumps({args.only: out}))
+        return
+
+    mpc, w = workloads.make_controller("cartpole", 10, True, device=dev_index)
     h = mpc._handle
     nv, nc, npar = _native.get_dims(h, 0)
     nx, nu, N = 4, 1, 10
     B = args.batch
 
-    # synthetic batch: trajectories are sharded, each rank draws its own seeded sample
-    S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
-    idx = np.random.default_rng(1000 + rank).integers(0, len(S), B)
-    x = torch.from_numpy(S[idx, :nx].copy()).to(dev)
-    r = torch.from_numpy(S[idx, nx:].copy()).to(dev)
-    u = torch.empty((B, N, nu), dtype=torch.float64, device=dev)
-    x0 = torch.empty((B, nx), dtype=torch.float64, device=dev)
-    ss = torch.empty((B, nx + nu), dtype=torch.float64, device=dev)
-    st = torch.empty(B, dtype=torch.int32, device=dev)
-    it = torch.empty(B, dtype=torch.int32, device=dev)
+    # synthetic batch: distinct closed-loop states, every rank its own seeded closed loops
+    T_h = 32
+    X, R, _ = workloads.harvest_closed_loop_states(mpc, w, (B + T_h - 1) // T_h, T_h, seed=1000 + rank)
+    X, R = X[:B], R[:B]
+    distinct = len(np.unique(np.c_[X, R], axis=0))
+    # The harvest is time-step-major (all transients first), and with two instances per resident wave the launch time depends
+    # on which instances happen to come last (0.53 ... 0.76 ms over random orders of these very states).  Eight seeded random
+    # orders of the same 4096 states are kept in HBM and the steps go round them, so `value` is the mean over orders.
+    NORD = 8
+    batches = []
+    for k in range(NORD):
+        perm = np.random.default_rng(2000 + 16 * rank + k).permutation(B)
+        batches.append(DeviceBatch(torch, dev, X[perm], R[perm], None, N, nu))
+    batch = batches[0]
     torch.cuda.synchronize()
-
-    def step():
-        _native.solve_batch_device(h, B, x.data_ptr(), r.data_ptr(), None, u.data_ptr(), x0.data_ptr(), ss.data_ptr(), None,
-                                   st.data_ptr(), it.data_ptr())
 
     def fence():
         _native.synchronize(h)
@@ -120,25 +231,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    from LinearMPCOverNetworks import montecarlo
-
     def gather_stats():
         # the only exchange of the path: per-trajectory statistics, gathered once per sweep
         # (RCCL all-gather over xGMI; 8 B per trajectory, latency-bound)
-        stats = torch.stack([st, it], dim=1).contiguous()
+        stats = torch.stack([batch.st, batch.it], dim=1).contiguous()
         if backend != "nccl":
             stats = stats.cpu()
         return montecarlo.gather_statistics(stats, world * B, rank, world)
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        batches[i % NORD].solve(_native, h)
+    batch.solve(_native, h)
     _native.synchronize(h)
     gather_stats()                      # warm the collective and torch's own kernels as well
     fence()
     _native.kernel_ms_total(h, reset=True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        batches[i % NORD].solve(_native, h)
     _native.synchronize(h)
     stats_all = gather_stats()
     fence()
@@ -151,53 +261,43 @@ def main():
     kern_ms, launches = _native.kernel_ms_total(h, reset=True)
     stats_np = stats_all.cpu().numpy()
     status_all, iters_all = stats_np[:, 0], stats_np[:, 1]
-    iters_local = it.cpu().numpy()
 
     if rank == 0:
         value = world * B * args.steps / elapsed
-        avg_kernel_s = kern_ms / max(launches, 1) * 1e-3
-        f_it = flops_per_iteration(nv, nc)
-        flops_launch = float(iters_local.sum()) * f_it
-        achieved = flops_launch / avg_kernel_s / 1e12
+        avg_ms = kern_ms / max(launches, 1)
+        roof, dims, opt, inf = roofline_entry(_native, h, batch, None, avg_ms)
         bytes_solve = 8 * (2 * nx) + 8 * (N * nu + nx + nx + nu) + 8      # inputs + the outputs this call writes + status/iters
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        roof["traffic"] = measured_traffic(roof["kernel"])
+        roof["note"] = ("bound is FP64 arithmetic (vector ALU + the FP64 MFMA normal-matrix pass; 78.6 TFLOP/s is the peak of "
+                        "either), not HBM: algorithmic HBM bytes are %d B/solve" % bytes_solve)
+        roof["hbm"] = {"achieved": bytes_solve * B / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                       "frac": bytes_solve * B / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         out = {
             "metric": "QP solves/sec (= MPC steps/sec) at batch",
             "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "cartpole n=4 m=1 N=10 tube-tracking QP, fixed x0, batch 4096 per GPU, "
-                                   "closed-loop transient (x_k, ref) pairs (BASELINE configs[1])",
-                       "batch_per_gpu": B, "nv": nv, "nc": nc, "parallelism": f"trajectory-sharded x{world}",
-                       "mean_ipm_iters": float(iters_all.mean()), "optimal_fraction": float((status_all == 0).mean())},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "tmpc::solve_kernel<12,2,6,7,false,%d>" % (8 if B > 1024 else 4), "avg_kernel_ms": avg_kernel_s * 1e3,
-                         "flops_per_launch": flops_launch,
-                         "note": "bound is FP64 arithmetic (vector ALU; 78.6 TFLOP/s is also the FP64 MFMA peak), "
-                                 "not HBM: algorithmic HBM bytes are %d B/solve" % bytes_solve,
-                         "hbm": {"achieved": bytes_solve * B / avg_kernel_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                 "frac": bytes_solve * B / avg_kernel_s / 1e9 / HBM_PEAK_GBPS}},
+            "config": {"workload": "cartpole n=4 m=1 N=10 tube-tracking QP, fixed x0, p_loss 0.3, batch 4096 per GPU: the (x_hat, ref) "
+                                   "pairs of 128 seeded closed loops x 32 steps over the lossy network (BASELINE configs[1])",
+                       "batch_per_gpu": B, "distinct_states": int(distinct), "nv": nv, "nc": nc,
+                       "parallelism": f"trajectory-sharded x{world}",
+                       "mean_ipm_iters": float(iters_all.mean()), "optimal_fraction": float((status_all == 0).mean()),
+                       "trivial_fraction": float((iters_all == 0).mean())},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
             orc = Oracle(mpc._problem_dict())
             cores = host_cores()
             ns = 131072
-            ii = np.random.default_rng(5).integers(0, len(S), ns)
-            Xc, Rc = S[ii, :nx].copy(), S[ii, nx:].copy()
+            ii = np.random.default_rng(5).integers(0, B, ns)
+            Xc, Rc = X[ii].copy(), R[ii].copy()
             orc.solve(Xc[:256], Rc[:256], nthreads=cores)
             tc = time.perf_counter()
             oc = orc.solve(Xc, Rc, nthreads=cores)
             tc = time.perf_counter() - tc
             out["cpu_baseline"] = {"value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
-                                   "sample": f"{ns} instances of the same workload, oracle/tmpc_oracle.c (IPM + refinement), "
+                                   "sample": f"{ns} instances drawn from the same 4096 states, oracle/tmpc_oracle.c (IPM + refinement), "
                                              f"OpenMP over the batch, {tc:.2f} s wall, mean iters {oc['iters'].mean():.2f}"}
             # the reference's Monte-Carlo loop body (results_linear_system.py:209-291) on the host cores: numpy state
             # machines around the same CPU solver, all trajectories of a time step solved together
@@ -217,24 +317,34 @@ def main():
                                                   "p_loss": 0.3, "note": "same loop as closed_loop below, solver and state machines on the host"}
         if world == 1 and not args.no_closed_loop:
             # the same kernel inside the device-resident closed loop over the lossy network (tmpc_mc_run): every step is
-            # the solve + the estimator / actuator / plant state machines, 4096 trajectories, p_loss = 0.3 (configs[1])
-            Tcl = 50
+            # the solve + the estimator / actuator / plant state machines, 4096 trajectories, p_loss = 0.3 (configs[1]);
+            # reference step at t = 0 and again half way, so that transients and settled phases are both in the run
+            Tcl = 100
             th, ga, wd = montecarlo.draw_realisations(B, Tcl, w["w_bound"], seed=99)
             pl = np.full(B, 0.3)
-            mpc.run_closed_loop(pl[:64], 0.5 * np.ones(Tcl), th[:64], ga[:64], wd[:64])          # warm-up
-            tcl = time.perf_counter()
-            cl = mpc.run_closed_loop(pl, 0.5 * np.ones(Tcl), th, ga, wd)
-            tcl = time.perf_counter() - tcl
-            out["closed_loop"] = {"value": B * Tcl / tcl, "unit": "MPC steps/s", "trajectories": B, "steps": Tcl, "p_loss": 0.3,
-                                  "tube_violations": int(cl["tube_violations"].sum()), "non_optimal_solves": int(cl["not_optimal"].sum()),
-                                  "note": "end to end incl. upload of the realisations and download of the statistics"}
+            ref_cl = np.where(np.arange(Tcl) < Tcl // 2, 0.5, -0.5)
+            mpc.run_closed_loop(pl[:64], ref_cl, th[:64], ga[:64], wd[:64])          # warm-up
+            cl_out = {}
+            for warm in (False, True):
+                tcl = time.perf_counter()
+                cl = mpc.run_closed_loop(pl, ref_cl, th, ga, wd, warm_start=warm)
+                tcl = time.perf_counter() - tcl
+                cl_out["warm" if warm else "cold"] = {
+                    "value": B * Tcl / tcl, "unit": "MPC steps/s", "tube_violations": int(cl["tube_violations"].sum()),
+                    "non_optimal_solves": int(cl["not_optimal"].sum()), "mean_ipm_iters": float(cl["iters_mean"]),
+                    "tracking_error_mean": float(cl["tracking_error"].mean())}
+            out["closed_loop"] = {"trajectories": B, "steps": Tcl, "p_loss": 0.3, **cl_out,
+                                  "note": "end to end incl. upload of the realisations and download of the statistics; warm = every "
+                                          "solve first tries the working set of the trajectory's previous step in the exact refinement"}
+        if world == 1 and not args.no_extras:
+            out["config3"] = config3_extra()
+            out["config5"] = config5_extra()
             # offline stage extra: support-function LPs over this workload's terminal set in one launch (tmpc_lp_batch)
-            from LinearMPCOverNetworks import _native as nat
             Xf = mpc._Xf
             dirs = np.random.default_rng(7).standard_normal((65536, Xf.A.shape[1]))
-            nat.lp_batch(Xf.A, Xf.b, dirs[:256])
+            _native.lp_batch(Xf.A, Xf.b, dirs[:256])
             tlp = time.perf_counter()
-            lp = nat.lp_batch(Xf.A, Xf.b, dirs)
+            lp = _native.lp_batch(Xf.A, Xf.b, dirs)
             tlp = time.perf_counter() - tlp
             out["offline_lp"] = {"value": len(dirs) / tlp, "unit": "LP/s", "rows": int(Xf.A.shape[0]), "dim": int(Xf.A.shape[1]),
                                  "batch": len(dirs), "solved": int((lp["status"] == 0).sum()),

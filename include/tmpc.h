@@ -192,11 +192,24 @@ const char *tmpc_kernel_name(const tmpc_handle *h, int variant);
  *        not_optimal B   solves with status != 0 (a solve with status >= 2 sends no packet)
  *        x_final     B*nx
  *        consistent  B   max |x_hat - x_nom| over the steps with Theta_t = gamma_t = 1 (0 by Proposition 1; not for extended)
+ *        iters_sum   B   interior-point iterations spent on the trajectory (the solve effort the reference's scripts report
+ *                        as times, results_linear_system.py:305-315)
  * All pointers are HOST pointers; the call returns when the results are in place.
  */
 int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
                 const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
-                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent);
+                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent,
+                int32_t *iters_sum);
+
+/*
+ * Warm start inside tmpc_mc_run (off by default).  Consecutive QPs of a trajectory share most of their active set: with
+ * on != 0 every solve first hands the working set certified by the trajectory's previous solve (of the same problem
+ * variant) to the active-set refinement.  The refinement accepts a point only if it is primal feasible on ALL rows with
+ * non-negative multipliers, i.e. only the exact minimiser; otherwise the solve falls back to the cold interior-point
+ * start.  Results are therefore the same with and without (tests/test_closed_loop.py); only the iteration counts drop.
+ * One-wave-per-QP kernel only; the workgroup-per-QP kernel ignores the setting.
+ */
+int tmpc_mc_set_warm_start(tmpc_handle *h, int on);
 
 /*
  * Plant simulated by tmpc_mc_run.  TMPC_PLANT_LINEAR (default): x+ = A x + B u + w (results_linear_system.py:248).

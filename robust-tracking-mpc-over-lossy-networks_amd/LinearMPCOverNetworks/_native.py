@@ -87,7 +87,9 @@ def lib():
         L.tmpc_get_kernel_path.restype = C.c_int
         L.tmpc_kernel_name.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_kernel_name.restype = C.c_char_p
-        L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 5
+        L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 6
+        L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_mc_set_warm_start.restype = C.c_int
         L.tmpc_mc_run.restype = C.c_int
         L.tmpc_mc_set_actuator.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_actuator.restype = C.c_int
@@ -285,8 +287,11 @@ def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
         raise RuntimeError(h.error())
 
 
-def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False) -> dict:
-    """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device."""
+def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False) -> dict:
+    """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device.
+    warm_start: tmpc_mc_set_warm_start for this call."""
+    if lib().tmpc_mc_set_warm_start(h.ptr, int(bool(warm_start))) != 0:
+        raise RuntimeError(h.error())
     c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     th_u, ga_u, w, p_loss, ref = c(th_u), c(ga_u), c(w), c(p_loss), c(ref)
     B, T = th_u.shape
@@ -299,15 +304,16 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
         HZ, hZ = c(Z.A), c(Z.b)
         rZ = HZ.shape[0]
     out = dict(err2=np.empty(B), tube_violations=np.empty(B, np.int32), not_optimal=np.empty(B, np.int32),
-               x_final=np.empty((B, h.nx)), consistent=np.empty(B))
+               x_final=np.empty((B, h.nx)), consistent=np.empty(B), iters_sum=np.empty(B, np.int32))
     ptr = lambda a: None if a is None else a.ctypes.data
     rc = lib().tmpc_mc_run(h.ptr, B, T, int(bool(extended)), ptr(p_loss), ptr(ref), ptr(th_u), ptr(ga_u), ptr(w), ptr(x0c),
                            ptr(HZ), ptr(hZ), rZ, ptr(out["err2"]), ptr(out["tube_violations"]), ptr(out["not_optimal"]),
-                           ptr(out["x_final"]), ptr(out["consistent"]))
+                           ptr(out["x_final"]), ptr(out["consistent"]), ptr(out["iters_sum"]))
     if rc != 0:
         raise RuntimeError(f"tmpc_mc_run failed ({rc}): {h.error()}")
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
+    out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve
     return out
 
 

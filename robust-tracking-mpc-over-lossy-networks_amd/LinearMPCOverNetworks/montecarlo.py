@@ -99,7 +99,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     ExtendedTubeTrackingMPC that is told whether the previous plant packet arrived (gamma_{t-1}, :276), the
     estimator is the RobustEstimator (it also stores x_nom_0, :279) and the actuator adopts x_nom_0 (:133-147).
 
-    p_loss (B,), ref (T,) position reference, th_u/ga_u (B,T) uniforms, w (B,T,nx) disturbances.
+    p_loss (B,), ref (T,) or (B,T) position reference, th_u/ga_u (B,T) uniforms, w (B,T,nx) disturbances.
     plant: None = the linear model x+ = A x + B u + w (:248); or a callable (x (B,nx), u (B,nu)) -> x+ (w is added to it),
     e.g. workloads.cartpole_step for the nonlinear cart-pole of results_nonlinear_system.py.
     Returns a dict of per-trajectory statistics."""
@@ -110,6 +110,10 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     nb, T = th_u.shape
     nx = A.shape[0]
     p_loss = np.asarray(p_loss, dtype=np.float64).reshape(nb)
+    ref = np.asarray(ref, dtype=np.float64)          # (T,) shared by the batch, or (B, T) per trajectory
+
+    def ref_at(t):
+        return ref[t] if ref.ndim == 1 else ref[:, t]
     x = np.zeros((nb, nx)) if x0 is None else np.array(x0, dtype=np.float64).reshape(nb, nx)
     est = BatchedEstimator(A, Bm, K, x, N, K_plant=K_plant if extended else None, robust=extended)
     act = BatchedConsistentActuator(A, Bm, K, K_plant, x, is_extended_MPC_used=extended)
@@ -122,7 +126,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     for t in range(T):
         theta = np.where(th_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :211-226, strict <
         r_t = np.zeros((nb, nx))
-        r_t[:, 0] = ref[t]
+        r_t[:, 0] = ref_at(t)
         q_t = est.get_qt()
         if extended:
             U_t, x_nom_0, status = packets_fn(est.get_estimate(), r_t, gamma.astype(np.uint8))     # RLX:276, gamma of step t-1
@@ -141,7 +145,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
         if extended:
             est.store_x_nom_0(x_nom_0)                                                             # RLX:279
         u, pkt = act.process(U_t, q_t, x, theta, x_nom_0 if extended else None)                    # :244
-        err2 += (x[:, 0] - ref[t]) ** 2 + np.sum(x[:, 1:] ** 2, axis=1)                            # :291 (x_t, t = 0..T-1)
+        err2 += (x[:, 0] - ref_at(t)) ** 2 + np.sum(x[:, 1:] ** 2, axis=1)                            # :291 (x_t, t = 0..T-1)
         # :258 -- plant state against the nominal state the actuator used at time t (for the extended controller:
         # after adopting the packet's x_nom_0, SmartActuator.py:219-222)
         x_nom_now = pkt["x_nom_t"] if extended else pkt["x_t"]
@@ -170,6 +174,10 @@ def run_remote_tracking_mpc(packets_fn, A, B, K, N, p_loss, ref, th_u, ga_u, w, 
     nb, T = th_u.shape
     nx = A.shape[0]
     p_loss = np.asarray(p_loss, dtype=np.float64).reshape(nb)
+    ref = np.asarray(ref, dtype=np.float64)          # (T,) shared by the batch, or (B, T) per trajectory
+
+    def ref_at(t):
+        return ref[t] if ref.ndim == 1 else ref[:, t]
     x = np.zeros((nb, nx)) if x0 is None else np.array(x0, dtype=np.float64).reshape(nb, nx)
     est = BatchedEstimator(A, Bm, K, x, N)
     act = BatchedConsistentActuator(A, Bm, K, np.zeros_like(np.atleast_2d(K)), x)     # no nominal model: x_nom := x each step
@@ -180,7 +188,7 @@ def run_remote_tracking_mpc(packets_fn, A, B, K, N, p_loss, ref, th_u, ga_u, w, 
     for t in range(T):
         theta = np.where(th_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)
         r_t = np.zeros((nb, nx))
-        r_t[:, 0] = ref[t]
+        r_t[:, 0] = ref_at(t)
         q_t = est.get_qt()
         U_t, _, status = packets_fn(est.get_estimate(), r_t)
         newly = ~dead & (status >= 2)
@@ -192,7 +200,7 @@ def run_remote_tracking_mpc(packets_fn, A, B, K, N, p_loss, ref, th_u, ga_u, w, 
         act.x_nom = x.copy()
         u, pkt = act.process(U_t, q_t, x, theta)
         pkt = {"x_t": x.copy(), "s_t": pkt["s_t"]}
-        err2 += np.where(dead, 0.0, (x[:, 0] - ref[t]) ** 2 + np.sum(x[:, 1:] ** 2, axis=1))
+        err2 += np.where(dead, 0.0, (x[:, 0] - ref_at(t)) ** 2 + np.sum(x[:, 1:] ** 2, axis=1))
         x = np.where(dead[:, None], x, x @ A.T + u @ Bm.T + w[:, t])
         gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)
         est.update(pkt, gamma)

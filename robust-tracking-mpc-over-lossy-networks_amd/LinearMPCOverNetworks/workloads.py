@@ -95,3 +95,63 @@ def cartpole_step(x, F, Th: float = 0.02, substeps: int = 10, par=CARTPOLE_PARAM
         k4 = cartpole_rhs(x + dt * k3, F, par)
         x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
     return x
+
+
+# --------------------------------------------------------------------------- controllers for the named workloads
+def make_controller(name: str = "cartpole", N: int = 10, fixed_initial_state: bool = True, extended: bool = False,
+                    device: int = 0, tracking: bool = False, verbose: bool = False):
+    """Controller of a BASELINE workload, set up the way the reference's scripts do it
+    (results_linear_system.py:113-128, Example_of_Tube_Tracking_MPC.py:46-53): constraints, then
+    `setup_optimization(W, fixed_initial_state, rpi_method)` -- mRPI, tightening, terminal set (and Z (-) W for the
+    extended controller) through the batched LP kernel on `device` (0.2 s for the cartpole), then the device-resident QP.
+    Returns (mpc, model dict).  tracking=True: the non-robust comparator TrackingMPC (results_linear_system.py:132-140)."""
+    import contextlib
+    import io
+    from . import polytope_lite
+    from .TrackingMPC import TrackingMPC
+    from .TubeTrackingMPC import ExtendedTubeTrackingMPC, TubeTrackingMPC
+    model = {"cartpole": cartpole, "double_integrator": double_integrator, "synthetic": synthetic}[name]()
+    cls = TrackingMPC if tracking else (ExtendedTubeTrackingMPC if extended else TubeTrackingMPC)
+    mpc = cls(model["A"], model["B"], model["Q"], model["R"], N)
+    mpc.set_input_constraints(model["U"])
+    mpc.set_state_constraints(model["X"])
+    mpc.set_device(device)
+    old = polytope_lite.set_lp_backend("hip", device)
+    try:
+        with (contextlib.nullcontext() if verbose else contextlib.redirect_stdout(io.StringIO())):     # the reference's progress prints
+            if tracking:
+                mpc.setup_optimization()
+            else:
+                # the double integrator example uses the default (Rakovic) mRPI, the result scripts pass rpi_method = 1 (Darup)
+                mpc.setup_optimization(model["W"], fixed_initial_state=fixed_initial_state,
+                                       rpi_method=0 if name == "double_integrator" else 1)
+    finally:
+        polytope_lite.set_lp_backend(old)
+    return mpc, model
+
+
+def harvest_closed_loop_states(mpc, model: dict, n_traj: int, T: int, seed: int = 0, extended: bool = False,
+                               p_loss: float = 0.3, ref_hold: int = 25, ref_range: float = 2.5):
+    """(x_hat_k, ref_k[, gamma_k]) triples the remote controller is actually asked to solve: `n_traj` closed loops over
+    the lossy network (montecarlo.run_remote_tube_mpc around this controller's own device solver), every trajectory with its
+    own piecewise-constant position reference (a new level every `ref_hold` steps, uniform in +-ref_range) and its own loss /
+    disturbance realisation.  Returns X (n_traj*T, nx), R (n_traj*T, nx), gamma (n_traj*T,) uint8 -- all distinct states,
+    transients and steady phases alike.  Synthetic input generator of bench.py and the scripts."""
+    from . import montecarlo
+    rng = np.random.default_rng(seed)
+    nx = model["A"].shape[0]
+    levels = rng.uniform(-ref_range, ref_range, (n_traj, (T + ref_hold - 1) // ref_hold))
+    refs = np.repeat(levels, ref_hold, axis=1)[:, :T]                       # (n_traj, T)
+    th, ga, w = montecarlo.draw_realisations(n_traj, T, model["w_bound"], seed=seed + 17)
+    Xs, Rs, Gs = [], [], []
+
+    def packets(x_hat, r_t, gamma=None):
+        Xs.append(np.array(x_hat, dtype=np.float64))
+        Rs.append(np.array(r_t, dtype=np.float64))
+        Gs.append(np.ones(len(x_hat), np.uint8) if gamma is None else np.array(gamma, dtype=np.uint8))
+        return mpc.determine_packets(x_hat, r_t, gamma) if gamma is not None else mpc.determine_packets(x_hat, r_t)
+
+    montecarlo.run_remote_tube_mpc(packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
+                                   mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, np.full(n_traj, p_loss), refs, th, ga, w,
+                                   extended=extended)
+    return np.concatenate(Xs), np.concatenate(Rs), np.concatenate(Gs)

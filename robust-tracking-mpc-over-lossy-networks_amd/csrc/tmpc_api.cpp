@@ -50,6 +50,8 @@ struct tmpc_handle {
     size_t mc_arena_bytes = 0;
     int plant = TMPC_PLANT_LINEAR, plant_substeps = 10;
     int actuator = TMPC_ACTUATOR_CONSISTENT;
+    tmpc::WorkCounter wc;        // work counters of the wave kernel's launches (tmpc_device.hpp)
+    int mc_warm = 0;             // closed loop: hand every solve the working set of the trajectory's previous solve of the same variant
     double plant_par[7] = {0, 0, 0, 0, 0, 0, 0};
     int kernel_path = TMPC_PATH_AUTO;
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
@@ -324,8 +326,7 @@ int ensure_staging(tmpc_handle *h, int64_t B) {
 }
 
 int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
-            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, const int32_t *ws_in = nullptr,
-            int32_t *ws_out = nullptr) {
+            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int32_t *const *ws = nullptr) {
     hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
     if (h->pool_used < 4096) {
         if (h->pool_used == h->pool.size()) {
@@ -352,7 +353,7 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
             continue;
         }
         HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
-                                      iters, ws_in, ws_out, h->n_cu, h->stream));
+                                      iters, ws ? ws[k] : nullptr, ws ? ws[k] : nullptr, &h->wc, h->n_cu, h->stream));
     }
     HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
     h->timed = true;
@@ -426,6 +427,9 @@ int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
                 h->n_cu = prop.multiProcessorCount;
                 auto setup = [&]() -> int {
                     HIP_TRY(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+                    h->wc.size = 4096;
+                    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->wc.ring), h->wc.size * sizeof(unsigned long long)));
+                    HIP_TRY(h, hipMemset(h->wc.ring, 0, h->wc.size * sizeof(unsigned long long)));
                     for (int i = 0; i < 256; ++i) {       // timing events are created up front, not in the solve path
                         hipEvent_t a = nullptr, b = nullptr;
                         HIP_TRY(h, hipEventCreate(&a));
@@ -461,7 +465,7 @@ void tmpc_destroy(tmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
     {
-        void *wsp[] = {h->blk_ws, h->mc_arena};
+        void *wsp[] = {h->blk_ws, h->mc_arena, h->wc.ring};
         for (void *q2 : wsp) if (q2) (void)hipFree(q2);
     }
     for (int k = 0; k < 2; ++k)
@@ -556,9 +560,16 @@ int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps
     return TMPC_OK;
 }
 
+int tmpc_mc_set_warm_start(tmpc_handle *h, int on) {
+    if (!h) return TMPC_E_INVALID;
+    h->mc_warm = on ? 1 : 0;
+    return TMPC_OK;
+}
+
 int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
                 const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
-                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent) {
+                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent,
+                int32_t *iters_sum) {
     if (!h) return TMPC_E_INVALID;
     if (B < 0 || T < 0 || !p_loss || !ref || !th_u || !ga_u || !w || (rZ > 0 && (!HZ || !hZ))) { h->err = "tmpc_mc_run: NULL argument"; return TMPC_E_INVALID; }
     if (h->device < 0) { h->err = "host-only handle (device < 0): nothing can be solved without the GPU"; return TMPC_E_DEVICE; }
@@ -572,7 +583,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
     const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + 2 * t_ + t_ * nx)) +
-                        8 * b * (6 * nx + (N + 1) * nu + nu + 2) + 4 * b * 7 + 2 * b;
+                        8 * b * (6 * nx + (N + 1) * nu + nu + 2) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE;
     if (need > h->mc_arena_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mc_arena) (void)hipFree(h->mc_arena);
@@ -624,6 +635,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             {reinterpret_cast<void **>(&st.q_act), b * 4, 0}, {reinterpret_cast<void **>(&st.s), b * 4, 0},
             {reinterpret_cast<void **>(&st.Theta), b * 4, 0}, {reinterpret_cast<void **>(&st.last_lost), b * 4, 0xFF},
             {reinterpret_cast<void **>(&st.tube_viol), b * 4, 0}, {reinterpret_cast<void **>(&st.not_optimal), b * 4, 0},
+            {reinterpret_cast<void **>(&st.iters_sum), b * 4, 0},
             {reinterpret_cast<void **>(&st.gamma), b, 1}, {reinterpret_cast<void **>(&st.dead), b, 0}};
         for (auto &a : arrays) {
             if ((r2 = dalloc(a.bytes, a.p))) return r2;
@@ -634,11 +646,20 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             HIP_TRY(h, hipMemcpyAsync(st.x_hat, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipMemcpyAsync(st.x_nom, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
         }
+        // warm start: one working-set record per trajectory and variant (row ids are per variant), updated in place by the
+        // solve kernel; m = 0 (the memset) means "nothing to start from"
+        int32_t *ws[2] = {nullptr, nullptr};
+        if (h->mc_warm) {
+            for (int k = 0; k < (extended ? 2 : 1); ++k) {
+                if ((r2 = dalloc(b * tmpc::WS_STRIDE * 4, reinterpret_cast<void **>(&ws[k])))) return r2;
+                HIP_TRY(h, hipMemsetAsync(ws[k], 0, b * tmpc::WS_STRIDE * 4, h->stream));
+            }
+        }
         for (int t = 0; t < T; ++t) {
             HIP_TRY(h, tmpc::launch_mc_pre(m, st, t, B, ref[t], h->stream));
-            int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it);
+            int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it, ws);
             if (r3) return r3;
-            HIP_TRY(h, tmpc::launch_mc_post(m, st, t, T, B, ref[t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->stream));
+            HIP_TRY(h, tmpc::launch_mc_post(m, st, t, T, B, ref[t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, h->stream));
             HIP_TRY(h, tmpc::launch_mc_tube(m, st, B, h->stream));
         }
         if (err2) HIP_TRY(h, hipMemcpyAsync(err2, st.err2, b * 8, hipMemcpyDeviceToHost, h->stream));
@@ -646,6 +667,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
         if (not_optimal) HIP_TRY(h, hipMemcpyAsync(not_optimal, st.not_optimal, b * 4, hipMemcpyDeviceToHost, h->stream));
         if (x_final) HIP_TRY(h, hipMemcpyAsync(x_final, st.x, b * nx * 8, hipMemcpyDeviceToHost, h->stream));
         if (consistent) HIP_TRY(h, hipMemcpyAsync(consistent, st.consistent, b * 8, hipMemcpyDeviceToHost, h->stream));
+        if (iters_sum) HIP_TRY(h, hipMemcpyAsync(iters_sum, st.iters_sum, b * 4, hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         return TMPC_OK;
     };

@@ -67,11 +67,19 @@ bool pick_config(int nv, int nd2, int nd1, int kc, int nc2, int nc1, KernelShape
 size_t lds_bytes(const KernelShape &shape);
 const char *kernel_name(const KernelShape &shape);
 
+// Work counters of the wave kernel's persistent grid: every launch draws its instances from a fresh, zeroed device word of
+// a ring that is cleared in one piece when it has gone round -- no reset and no extra stream operation per launch.
+// Launches that share a ring must be ordered on one stream.
+struct WorkCounter {
+    unsigned long long *ring = nullptr;
+    int size = 0, pos = 0;
+};
+
 // ws_in / ws_out: optional working sets (WS_STRIDE ints per instance), see above
 hipError_t launch_solve(const DeviceQP &qp, const KernelShape &shape, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out,
-                        int n_cu, hipStream_t stream);
+                        WorkCounter *wc, int n_cu, hipStream_t stream);
 
 // Block path: tiles = NVP / 16 in {1, 2, 4, 8} (0: nv > 128, unsupported); workspace = blocks * rows * ncp doubles
 int block_tiles(int nv);
@@ -98,7 +106,7 @@ struct McState {                         // all [trajectory]-major device arrays
     double *ref_k;                       // reference handed to the solve                                       [B][nx]
     double *e_buf;                       // x_t - x_nom_t of the current step, for the tube membership kernel    [B][nx]
     double *err2, *consistent;           // statistics                                                          [B]
-    int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal;
+    int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal, *iters_sum;
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
     uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
@@ -106,7 +114,7 @@ struct McState {                         // all [trajectory]-major device arrays
 hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream);
 hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStream_t stream);
 hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
-                          const double *x_nom0, const double *xu_ss, const int32_t *status, hipStream_t stream);
+                          const double *x_nom0, const double *xu_ss, const int32_t *status, const int32_t *iters, hipStream_t stream);
 
 // LP kernel (tmpc_lp.hip): rows scaled to unit norm, h scaled by hm so that max |h| = 1
 struct LpDevice {

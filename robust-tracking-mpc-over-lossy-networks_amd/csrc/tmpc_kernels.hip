@@ -342,7 +342,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters,
-    const int32_t *__restrict__ ws_in, int32_t *__restrict__ ws_out) {
+    const int32_t *__restrict__ ws_in, int32_t *__restrict__ ws_out, unsigned long long *__restrict__ next_item) {
     using SH = Shape<NV, DP, DS, KC, CP, CS, (WPB == 8 ? 12 : 16)>;
     using WL = WaveLds<SH>;
     constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, KT = SH::KT, WCAP = SH::WCAP, LDG = SH::LDG;
@@ -357,7 +357,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const int tid = threadIdx.x;
     const int lane_k = tid & (WAVE - 1);
     int lane = lane_k;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: the workspace addresses stay scalar
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nc = qp.nc;
 
     // ---- stage the shared model once per workgroup (coalesced, L2-resident source)
@@ -393,10 +393,31 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     auto valid = [&](int i) { return ((vmask >> i) & 1u) != 0u; };
 #define TMPC_REFRESH() do { lane = fresh(lane_k); vmask = static_cast<unsigned>(fresh(vmask_k)); } while (0)
 
-    const int64_t wave_global = static_cast<int64_t>(blockIdx.x) * WPB + wave;
-    const int64_t wave_stride = static_cast<int64_t>(gridDim.x) * WPB;
-
-    for (int64_t b = wave_global; b < B; b += wave_stride) {
+    // Work distribution: the waves of the persistent grid draw instances from one counter (zeroed by the host before the
+    // launch).  The cost of an instance varies by 2 x cold (10 ... 19 interior-point iterations) and by 5 x in the
+    // warm-started closed loop (refinement only, or refinement + cold solve), so a static split leaves most SIMDs idle
+    // while the unluckiest finishes.  Every wave leaves the loop at its first draw >= B.
+    // The first instance of a wave is fixed (its index in the grid): two thousand simultaneous draws on one word at kernel
+    // start cost more than the balance gains; the later draws are spread over time by the very imbalance they repair.
+    const int64_t n_waves = static_cast<int64_t>(gridDim.x) * WPB;
+    bool first_item = true;
+    for (;;) {
+        int64_t b;
+        if (first_item) {
+            b = static_cast<int64_t>(blockIdx.x) * WPB + wave;
+            first_item = false;
+        } else {
+            // a plain look first: at the end of the launch every wave would otherwise add one failing draw to a burst of
+            // two thousand on the same word (device-scope atomics on one address retire at some 15 per microsecond)
+            unsigned long long drawn = ~0ull >> 2;
+            if (lane_k == 0) {
+                const unsigned long long seen = __hip_atomic_load(next_item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n_waves + static_cast<int64_t>(seen) < B) drawn = atomicAdd(next_item, 1ull);
+            }
+            b = n_waves + static_cast<int64_t>((static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(drawn >> 32)))) << 32) |
+                                               static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(drawn & 0xffffffffull))));
+        }
+        if (b >= B) break;
         if (variant != nullptr && variant[b] != variant_id) continue;
         if (variant == nullptr && variant_id != 0) continue;
 
@@ -444,6 +465,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         double qn = 1.0;
 #pragma unroll
         for (int j = 0; j < NV; ++j) qn = fmax(qn, fabs(qv[j]));
+        qn = readlane_d(qn, 0);              // (every lane holds the same value: keep it in scalar registers for the whole solve)
 
         // z = -Hinv q  -> zv, Psi z -> czv
         auto unconstrained_minimiser = [&]() {
@@ -651,7 +673,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             gn = fmax(gn, fabs(glj));
                         }
                         if (!(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
-                        if (near && rdn <= 1e3 * try_tol * qn) { want_polish = true; rdn_last = rdn; break; }
+                        if (near && rdn <= 1e3 * try_tol * qn) { want_polish = true; rdn_last = readlane_d(rdn, 0); break; }
                         if (lmax > 1e10) {
                             // Farkas-type certificate: lam blows up, G'lam -> 0, h'lam < 0
                             double hl = 0.0;       // (h is formed on the fly: its LDS region holds r_p here)
@@ -963,10 +985,13 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             T[i * WCAP + k] = v;
                         }
                         wave_lds_fence();
+                        // S = G_W T, its LDL' and the Newton steps, compiled for working sets of at most 12 rows (the common case: the
+                        // fully unrolled elimination costs MC^2 / 2 broadcasts whatever m is) and for the full capacity
+                        auto solve_working_set = [&]<int MC>(std::integral_constant<int, MC>) -> bool {
                         TMPC_REFRESH();
                         // S = G_W T (+ delta I) by rows in registers: lane a holds row a (identity rows beyond m); LDL' by
                         // readlane elimination like the normal matrix
-                        double srow[WCAP], sdinv = 1.0;
+                        double srow[MC], sdinv = 1.0;
                         {
                             double gw[NV];
                             const int la = lane < m ? lane : 0;
@@ -974,7 +999,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             for (int j = 0; j < NV; ++j) gw[j] = GW[la * NV + j];
                             double sdiag = 0.0;
 #pragma unroll
-                            for (int c2 = 0; c2 < WCAP; ++c2) {
+                            for (int c2 = 0; c2 < MC; ++c2) {
                                 double v = 0.0;
 #pragma unroll
                                 for (int j = 0; j < NV; ++j) v += gw[j] * T[j * WCAP + c2];
@@ -984,11 +1009,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             }
                             const double dmax = wave_max(sdiag);
 #pragma unroll
-                            for (int c2 = 0; c2 < WCAP; ++c2) if (c2 == lane && lane < m) srow[c2] += 1e-11 * dmax;
+                            for (int c2 = 0; c2 < MC; ++c2) if (c2 == lane && lane < m) srow[c2] += 1e-11 * dmax;
                         }
                         {
                             double bdummy = 0.0;
-                            if (!rows_factor<WCAP>(srow, bdummy, sdinv, lane)) break;
+                            if (!rows_factor<MC>(srow, bdummy, sdinv, lane)) return false;
                         }
                         // proximal Newton steps on the KKT system of the working set (at most twelve -- nearly parallel working rows need them --; they stop once a step
                         // no longer moves the iterate)
@@ -1019,8 +1044,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 for (int j = 0; j < NV; ++j) { const double g = GW[lane * NV + j]; gz += g * zpv[j]; gt += g * uv[j]; }
                                 bb = gz - hw[Widx[lane]] - gt;
                             }
-                            rows_forward<WCAP>(srow, bb, lane);
-                            const double dyl = rows_backsub_lane<WCAP>(srow, bb, sdinv, lane);
+                            rows_forward<MC>(srow, bb, lane);
+                            const double dyl = rows_backsub_lane<MC>(srow, bb, sdinv, lane);
                             if (lane < m) { dyv[lane] = dyl; yv[lane] += dyl; }
                             wave_lds_fence();
                             // zp -= t1 + T dy  (lane j -> entry j)
@@ -1036,6 +1061,13 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const double dzn = wave_max(dzl), zn = wave_max(fabs(zl));
                             if (stp >= 1 && dzn <= 1e-14 * fmax(zn, 1.0)) break;
                         }
+                            return true;
+                        };
+                        bool fact_ok;
+                        if (m <= 12) fact_ok = solve_working_set(std::integral_constant<int, 12>{});
+                        else if (WCAP == 24 || m <= 24) fact_ok = solve_working_set(std::integral_constant<int, 24>{});
+                        else fact_ok = solve_working_set(std::integral_constant<int, WCAP>{});
+                        if (!fact_ok) break;
                     }
                     // ---- verify: primal feasibility on all rows, sign of y on W
                     TMPC_REFRESH();
@@ -1188,7 +1220,8 @@ constexpr int waves_per_block() {
 template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
 hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
-                      int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, int n_cu, hipStream_t stream) {
+                      int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, WorkCounter *wc, int n_cu,
+                      hipStream_t stream) {
     using SH = Shape<NV, DP, DS, KC, CP, CS, (WPB == 8 ? 12 : 16)>;
     constexpr size_t lds = kernel_lds_bytes<SH>(WPB);
     static_assert(lds <= 160 * 1024, "shape does not fit the 160 KiB LDS of a CU");
@@ -1209,8 +1242,16 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     const int64_t cap = static_cast<int64_t>(n_cu);
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    // every launch gets a fresh (zero) word of the counter ring; the ring is cleared in one piece when it has gone round
+    if (wc->pos >= wc->size) {
+        hipError_t e0 = hipMemsetAsync(wc->ring, 0, sizeof(unsigned long long) * wc->size, stream);
+        if (e0 != hipSuccess) return e0;
+        wc->pos = 0;
+    }
     hipLaunchKernelGGL((solve_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
-                       qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out);
+                       qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
+                       wc->ring + wc->pos);
+    ++wc->pos;
     return hipGetLastError();
 }
 
@@ -1273,11 +1314,11 @@ bool pick_config(int nv, int nd2, int nd1, int kc, int nc2, int nc1, KernelShape
 hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out,
-                        int n_cu, hipStream_t stream) {
+                        WorkCounter *wc, int n_cu, hipStream_t stream) {
 #define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
         return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>()>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, \
-                                                                                   xu_ss, x_nom, status, iters, ws_in, ws_out, n_cu, stream);
+                                                                                   xu_ss, x_nom, status, iters, ws_in, ws_out, wc, n_cu, stream);
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE
     return hipErrorInvalidValue;

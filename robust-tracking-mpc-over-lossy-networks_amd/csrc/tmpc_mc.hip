@@ -49,7 +49,8 @@ __global__ void mc_pre_kernel(const McModel m, const McState st, const int t, co
 
 __global__ void mc_post_kernel(const McModel m, const McState st, const int t, const int T, const int64_t B, const double ref_t,
                                const double *__restrict__ u_nom, const double *__restrict__ x_nom0,
-                               const double *__restrict__ xu_ss, const int32_t *__restrict__ status) {
+                               const double *__restrict__ xu_ss, const int32_t *__restrict__ status,
+                               const int32_t *__restrict__ iters) {
     const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const int nx = m.nx, nu = m.nu, N = m.N;
@@ -59,6 +60,7 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     const int stat = status[b];
     const bool bad = stat >= 2;
     if (stat != 0) st.not_optimal[b] += 1;
+    st.iters_sum[b] += iters[b];                                                          // results_linear_system.py:305-315 report solve effort
     if (bad) theta = 0;            // a failed solve sends nothing (the reference's tube branch would raise here)
     if (m.smart && bad) {          // R-MPC branch: the trajectory ends here (:268-270), its tracking error is NaN (:297)
         st.dead[b] = 1;
@@ -203,11 +205,11 @@ hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, 
 }
 
 hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
-                          const double *x_nom0, const double *xu_ss, const int32_t *status, hipStream_t stream) {
+                          const double *x_nom0, const double *xu_ss, const int32_t *status, const int32_t *iters, hipStream_t stream) {
     if (m.nx > MAXN || m.nu > MAXN) return hipErrorInvalidValue;
     const int threads = 64;
     const unsigned blocks = static_cast<unsigned>((B + threads - 1) / threads);
-    hipLaunchKernelGGL(mc_post_kernel, dim3(blocks), dim3(threads), 0, stream, m, st, t, T, B, ref_t, u_nom, x_nom0, xu_ss, status);
+    hipLaunchKernelGGL(mc_post_kernel, dim3(blocks), dim3(threads), 0, stream, m, st, t, T, B, ref_t, u_nom, x_nom0, xu_ss, status, iters);
     return hipGetLastError();
 }
 

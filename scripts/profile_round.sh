@@ -1,14 +1,28 @@
 #!/bin/bash
-# Round-end profile of the bench command: kernel-trace stats + PMC passes (separate runs).
+# Round-end profiles: kernel-trace stats + PMC passes (separate runs; never combined with trace domains).
 # Usage (on the GPU box): bash scripts/profile_round.sh <tag>
-tag=${1:-r01}
+tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-closed-loop > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
-run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-closed-loop > gpurun_out/pmc_${tag}_$name.log 2>&1; }
+BENCH="python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-closed-loop --no-extras"
+# ---- the bench kernel (BASELINE configs[1])
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $BENCH > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
+run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-closed-loop --no-extras > gpurun_out/pmc_${tag}_$name.log 2>&1; }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES
 run sq2 SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_SCA SQ_INSTS_FLAT
+run mfma SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES
 run fetch FETCH_SIZE
 run write WRITE_SIZE
-python3 scripts/pmc_summary.py gpurun_out/pmc_${tag}_sq1 gpurun_out/pmc_${tag}_sq2 gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write > gpurun_out/pmc_${tag}_summary.txt
+python3 scripts/pmc_summary.py solve_kernel gpurun_out/pmc_${tag}_sq1 gpurun_out/pmc_${tag}_sq2 gpurun_out/pmc_${tag}_mfma gpurun_out/pmc_${tag}_fetch gpurun_out/pmc_${tag}_write > gpurun_out/pmc_${tag}_summary.txt
 cat gpurun_out/pmc_${tag}_summary.txt
-find gpurun_out/prof_$tag -name "*kernel_stats.csv" -exec cat {} \; | cut -c1-260
+find gpurun_out/prof_$tag -name "*kernel_stats.csv" -exec cat {} \; | cut -c1-200 > gpurun_out/prof_${tag}_kernel_stats.csv
+head -4 gpurun_out/prof_${tag}_kernel_stats.csv
+# ---- configs[2] (N = 20 extended controller, batch 65536) and configs[4] (n = 12, m = 4, N = 30, batch 16384: block kernel, MFMA)
+for cfg in config3 config5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_$cfg -- python3 bench.py --only $cfg > gpurun_out/prof_${tag}_$cfg.json 2> gpurun_out/prof_${tag}_$cfg.err
+  find gpurun_out/prof_${tag}_$cfg -name "*kernel_stats.csv" -exec cat {} \; | cut -c1-200 > gpurun_out/prof_${tag}_${cfg}_kernel_stats.csv
+  head -4 gpurun_out/prof_${tag}_${cfg}_kernel_stats.csv
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA --output-format csv -d gpurun_out/pmc_${tag}_${cfg}_a -- python3 bench.py --only $cfg > gpurun_out/pmc_${tag}_${cfg}_a.log 2>&1
+  rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc_${tag}_${cfg}_b -- python3 bench.py --only $cfg > gpurun_out/pmc_${tag}_${cfg}_b.log 2>&1
+  python3 scripts/pmc_summary.py solve_ gpurun_out/pmc_${tag}_${cfg}_a gpurun_out/pmc_${tag}_${cfg}_b > gpurun_out/pmc_${tag}_${cfg}_summary.txt
+  cat gpurun_out/pmc_${tag}_${cfg}_summary.txt
+done

@@ -211,3 +211,27 @@ def test_reference_streams_replay_on_device(hip_lib):
     assert dev["consistent_estimate_error"] < 1e-9                                  # Proposition 1 of the paper
     # p_loss = 0 never drops a packet (strict <, :218): every loss-free run of the replay tracks identically up to the disturbance
     assert np.ptp(dev["tracking_error"][:n_mc]) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extended,N", [(False, 10), (False, 20), (True, 10)])
+def test_warm_started_loop_equals_cold_loop(hip_lib, extended, N):
+    """tmpc_mc_set_warm_start: every solve first tries the working set of the trajectory's previous solve in the exact
+    refinement.  Accepted points are exact minimisers, rejected ones fall back to the cold start -- so the closed loop is the
+    same to 1e-8, while the interior-point iterations per solve drop."""
+    nb, T = 256, 120
+    mpc, w = common.make_mpc("cartpole", N, True, extended=extended, create=True)
+    p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=41)
+    ref = np.where(np.arange(T) < T // 2, 0.5, -0.3)
+    cold = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended)
+    warm = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended, warm_start=True)
+    assert np.all(cold["not_optimal"] == 0) and np.all(warm["not_optimal"] == 0)
+    assert np.array_equal(cold["tube_violations"], warm["tube_violations"])
+    np.testing.assert_allclose(warm["x_final"], cold["x_final"], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(warm["tracking_error"], cold["tracking_error"], atol=1e-10, rtol=0)
+    print(f"mean interior-point iterations per solve: cold {cold['iters_mean']:.2f}, warm {warm['iters_mean']:.2f}")
+    assert warm["iters_mean"] < 0.6 * cold["iters_mean"]
+    # the setting is per call: the next cold call is cold again
+    again = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended)
+    assert np.array_equal(again["iters_sum"], cold["iters_sum"])
