@@ -143,6 +143,13 @@ int tmpc_solve_batch(tmpc_handle *h, int64_t B,
  * tensor's data_ptr()).  The kernels are enqueued on the handle's stream and the
  * call returns without synchronising; use tmpc_synchronize() or
  * tmpc_last_kernel_ms().
+ *
+ * Ordering contract: the handle's stream is its own non-blocking stream; it is NOT ordered against
+ * the stream that produced the inputs or will consume the outputs (e.g. torch's current stream).
+ * The caller synchronises on both sides: the producers of x_k / ref / variant must have completed
+ * before this call (torch.cuda.synchronize() or an event wait), and the outputs may be read only
+ * after tmpc_synchronize().  Instances whose variant id is >= the handle's number of problems get
+ * status TMPC_STATUS_NUMERICAL and NaN outputs.
  */
 int tmpc_solve_batch_device(tmpc_handle *h, int64_t B,
                             const double *x_k, const double *ref, const uint8_t *variant,

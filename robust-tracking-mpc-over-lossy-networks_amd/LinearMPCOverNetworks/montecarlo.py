@@ -144,11 +144,12 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
         est.store(U_t)                                                                             # :242
         if extended:
             est.store_x_nom_0(x_nom_0)                                                             # RLX:279
+        x_nom_now = act.x_nom.copy()       # the nominal state the scripts test against: column t of x_nom_traj, i.e. BEFORE process_packet
         u, pkt = act.process(U_t, q_t, x, theta, x_nom_0 if extended else None)                    # :244
         err2 += (x[:, 0] - ref_at(t)) ** 2 + np.sum(x[:, 1:] ** 2, axis=1)                            # :291 (x_t, t = 0..T-1)
-        # :258 -- plant state against the nominal state the actuator used at time t (for the extended controller:
-        # after adopting the packet's x_nom_0, SmartActuator.py:219-222)
-        x_nom_now = pkt["x_nom_t"] if extended else pkt["x_t"]
+        # :258 / results_linear_system_with_extendedMPC.py:310-318,331-333 -- x_traj[:, t] - x_nom_traj[:, t]: the nominal state
+        # appended after the PREVIOUS step's process_packet, so for the extended controller the state before this step's
+        # adoption of x_nom_0 (SmartActuator.py:219-222); for the plain tube MPC the two coincide
         tube_viol += ~np.asarray(Z.contains((x - x_nom_now).T)).reshape(nb)
         x = (x @ A.T + u @ Bm.T if plant is None else plant(x, u)) + w[:, t]                      # :248
         gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :218-226
@@ -220,7 +221,7 @@ def plant_callable(plant):
 
 
 def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
-             extended: bool = False, device=None, on_device: bool = False, plant=None):
+             extended: bool = False, device=None, on_device: bool = False, plant=None, warm_start: bool = False):
     """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
     trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
     shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
@@ -234,7 +235,11 @@ def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240
     th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
     ref = np.broadcast_to(np.asarray(ref, dtype=np.float64), (T,))
     if on_device:        # state machines on the GPU as well (tmpc_mc_run); otherwise the host loop around determine_packets
-        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended, plant=plant)
+        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended, plant=plant, warm_start=warm_start)
+    elif getattr(mpc, "_smart_actuator", False):       # TrackingMPC: the comparator's loop (results_linear_system.py:262-287)
+        out = run_remote_tracking_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(), mpc._N,
+                                      p_loss[pi[lo:hi]], ref, th, ga, w)
+        out["tube_violations"] = np.zeros(hi - lo, dtype=np.int32)
     else:
         out = run_remote_tube_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
                                   mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, p_loss[pi[lo:hi]], ref, th, ga, w,

@@ -161,7 +161,20 @@ def lp_max_batch(C, A, b, relax=None, relax_by: float = 1.0, want_x: bool = Fals
                              f'dimension {A.shape[1]}: call set_lp_backend("scipy") for it')
         from . import _native
         out = _native.lp_batch(A, b, C, relax=rel, relax_by=relax_by, device=_LP_DEVICE, want_x=want_x)
-        st = np.select([out["status"] <= 1, out["status"] == 2, out["status"] == 4], [0, 2, 3], default=4).astype(int)
+        st = np.select([out["status"] == 0, out["status"] == 1, out["status"] == 2, out["status"] == 4], [0, 1, 2, 3], default=4).astype(int)
+        # kernel status 1: the interior-point iterate was returned without its vertex certificate (about 1 LP in 1 600, error
+        # ~1e-7).  These values feed the constraint tightening, so such an LP is solved again by HiGHS -- the call the
+        # reference makes for every LP (utils_polytope.py:19) -- instead of being passed on as "solved".
+        for k in np.flatnonzero(st == 1):
+            bk = b
+            if rel[k] >= 0:
+                bk = b.copy()
+                bk[rel[k]] += relax_by
+            res = linprog(-C[k], A_ub=A, b_ub=bk, bounds=(None, None), method="highs")
+            st[k] = res.status
+            out["val"][k] = -res.fun if res.status == 0 else (np.inf if res.status == 3 else np.nan)
+            if want_x:
+                out["x"][k] = res.x if res.status == 0 else np.nan
         return (out["val"], st, out["x"]) if want_x else (out["val"], st)
     val = np.empty(nb)
     st = np.zeros(nb, dtype=int)

@@ -341,6 +341,9 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     }
     h->ev0 = e0; h->ev1 = e1;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    if (variant != nullptr)
+        HIP_TRY(h, tmpc::launch_mark_invalid_variants(variant, h->nvariants, B, h->nx, h->nu, h->N, u_nom, x_nom0, xu_ss, x_nom, status,
+                                                      iters, h->stream));
     for (int k = 0; k < h->nvariants; ++k) {
         if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
         Variant &v = h->v[k];

@@ -613,9 +613,13 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         spd = block_chol<T>(big, LDM, nv, dinv, red + 16, tid);
                         BSTAMP(5);
                         if (!spd) {
+                            // 1e-13 * trace(M), as the oracle does: trace(G'DG) = sum of the weights (unit rows)
                             double trc = 0.0;
                             for (int i = 0; i < nv; ++i) trc += qp.Hs[i * NVP + i];
-                            shift = 1e-13 * (trc + lmax);
+                            double dsum = 0.0;
+                            for (int r = tid; r < nc; r += BT) dsum += d_[r];
+                            dsum = block_reduce1<OpSum>(dsum, red, wave, lane);
+                            shift = 1e-13 * (trc + dsum);
                         }
                     }
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             dmax = block_reduce1<OpMax>(dmax, red, wave, lane);
                             if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
                             if (!block_chol<(WCAP + 15) / 16>(S, LDSS, m, dinv, red + 16, tid)) break;
-                            for (int stp = 0; stp < 4; ++stp) {
+                            for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
                                 if (tid < NVP) {
                                     double v = qv[tid];

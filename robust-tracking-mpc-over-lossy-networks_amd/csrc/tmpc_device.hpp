@@ -111,6 +111,9 @@ struct McState {                         // all [trajectory]-major device arrays
     uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
 };
+hipError_t launch_mark_invalid_variants(const uint8_t *variant, int nvariants, int64_t B, int nx, int nu, int N, double *u_nom,
+                                        double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters,
+                                        hipStream_t stream);
 hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream);
 hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStream_t stream);
 hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,

@@ -1112,8 +1112,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     }
                     wave_lds_fence();
 #ifdef TMPC_DEBUG_PRINT
-                    if (lane == 0) {
-                        printf("b %lld tol %.1e it %d round %d m %d nviol %d nneg %d nloose %d ymax %.3e W:", (long long)b, try_tol, it_done, round, m, nviol, nneg, nloose, ymax);
+                    if (lane == 0 && b < 2) {
+                        printf("b %lld warm %d tol %.1e it %d round %d m %d nviol %d nneg %d nloose %d ymax %.3e W:", (long long)b, (int)try_warm, try_tol, it_done, round, m, nviol, nneg, nloose, ymax);
                         for (int k = 0; k < m && k < WCAP; ++k) printf(" %d(%.2e)", Widx[k], yv[k]);
                         printf("\n");
                     }
@@ -1123,7 +1123,12 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     // are inconsistent at the 1e-9 level.  The loose row with the weakest multiplier leaves; if it belongs to the
                     // active set after all, the check of all rows brings it back.  (With wrong rows still in W looseness is
                     // expected: correct W first.)
+                    // A handed-in working set is worth two or three corrections, not more: when it is far from the new active set the
+                    // corrections add dependent rows, the multipliers explode and ten rounds cost more than the cold solve they
+                    // were meant to save (seen right after reference steps).
+                    if (try_warm && !(nviol == 0 && nneg == 0) && (round >= 2 || nviol + nneg > 6 || nloose != 0)) break;
                     if (nloose != 0 && nviol == 0 && nneg == 0) {
+                        if (try_warm) break;
                         const double ymin = wave_min(yloose);
 #pragma unroll
                         for (int i = 0; i < RS; ++i)

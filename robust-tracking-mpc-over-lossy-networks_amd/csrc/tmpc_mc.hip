@@ -70,6 +70,11 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
 
     double x[MAXN], xn[MAXN], e[MAXN];
     for (int i = 0; i < nx; ++i) x[i] = st.x[b * nx + i];
+    // The tube statistic of the scripts is x_traj[:, t] - x_nom_traj[:, t] (results_linear_system.py:258,
+    // results_linear_system_with_extendedMPC.py:331): the nominal state appended after the PREVIOUS step's process_packet,
+    // i.e. before this step's adoption of x_nom_0 by the extended controller's actuator.  (The plain smart actuator has no
+    // nominal model: its "nominal" state is the measured one.)
+    for (int i = 0; i < nx; ++i) st.e_buf[b * nx + i] = m.smart ? 0.0 : x[i] - st.x_nom[b * nx + i];
     if (!bad) {
         for (int j = 0; j < nu; ++j) st.u_latest0[b * nu + j] = u_nom[b * N * nu + j];
         for (int i = 0; i < nx; ++i) st.x_nom0_latest[b * nx + i] = x_nom0[b * nx + i];
@@ -110,9 +115,8 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
         double a = (x[0] - ref_t) * (x[0] - ref_t);
         for (int i = 1; i < nx; ++i) a += x[i] * x[i];
         st.err2[b] += a;
-        // x_t - x_nom_t in Z (:258) is checked by mc_tube_kernel (rZ rows x nx columns per trajectory: too long a loop for
-        // one thread of this kernel, which only has a wave's worth of parallelism per 64 trajectories)
-        for (int i = 0; i < nx; ++i) st.e_buf[b * nx + i] = e[i];
+        // x_t - x_nom_t in Z (:258) is checked by mc_tube_kernel on e_buf (rZ rows x nx columns per trajectory: too long a loop
+        // for one thread of this kernel, which only has a wave's worth of parallelism per 64 trajectories)
     }
     // ---- plant and nominal model
     double xp[MAXN], xnp[MAXN];
@@ -194,6 +198,32 @@ __global__ void mc_tube_kernel(const McModel m, const McState st, const int64_t 
 hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStream_t stream) {
     if (m.rZ <= 0) return hipSuccess;
     hipLaunchKernelGGL(mc_tube_kernel, dim3(static_cast<unsigned>(B)), dim3(128), 0, stream, m, st, B);
+    return hipGetLastError();
+}
+
+// Instances whose variant id names no problem of the handle are solved by no kernel: they get status NUMERICAL and NaN
+// outputs instead of whatever the output buffers held.
+__global__ void mark_invalid_variants_kernel(const uint8_t *__restrict__ variant, const int nvariants, const int64_t B, const int nun,
+                                             const int nx, const int nxu, const int nxn, double *__restrict__ u_nom,
+                                             double *__restrict__ x_nom0, double *__restrict__ xu_ss, double *__restrict__ x_nom,
+                                             int32_t *__restrict__ status, int32_t *__restrict__ iters) {
+    const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (b >= B || variant[b] < nvariants) return;
+    const double nanv = __longlong_as_double(0x7ff8000000000000ll);
+    for (int i = 0; i < nun; ++i) u_nom[b * nun + i] = nanv;
+    if (x_nom0) for (int i = 0; i < nx; ++i) x_nom0[b * nx + i] = nanv;
+    if (xu_ss) for (int i = 0; i < nxu; ++i) xu_ss[b * nxu + i] = nanv;
+    if (x_nom) for (int i = 0; i < nxn; ++i) x_nom[b * nxn + i] = nanv;
+    status[b] = TMPC_STATUS_NUMERICAL;
+    iters[b] = 0;
+}
+hipError_t launch_mark_invalid_variants(const uint8_t *variant, int nvariants, int64_t B, int nx, int nu, int N, double *u_nom,
+                                        double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters,
+                                        hipStream_t stream) {
+    const int threads = 256;
+    const unsigned blocks = static_cast<unsigned>((B + threads - 1) / threads);
+    hipLaunchKernelGGL(mark_invalid_variants_kernel, dim3(blocks), dim3(threads), 0, stream, variant, nvariants, B, N * nu, nx, nx + nu,
+                       (N + 1) * nx, u_nom, x_nom0, xu_ss, x_nom, status, iters);
     return hipGetLastError();
 }
 

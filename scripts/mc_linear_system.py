@@ -12,9 +12,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
-import common  # noqa: E402  (cached offline sets of the cartpole)
-from LinearMPCOverNetworks import montecarlo  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "robust-tracking-mpc-over-lossy-networks_amd"))
+from LinearMPCOverNetworks import montecarlo, workloads  # noqa: E402
 
 
 def main():
@@ -24,6 +23,9 @@ def main():
     ap.add_argument("--N", type=int, default=20)               # :64
     ap.add_argument("--ref", type=float, default=0.5)          # :160
     ap.add_argument("--extended", action="store_true")
+    ap.add_argument("--rmpc", action="store_true", help="the non-robust comparator TrackingMPC (results_linear_system.py:132-140, 262-287) "
+                                                        "instead of the tube MPC; reports the infeasible runs per loss rate (:268-270)")
+    ap.add_argument("--warm-start", action="store_true", help="tmpc_mc_set_warm_start: previous working set first")
     ap.add_argument("--host-loop", action="store_true", help="state machines in numpy on the host instead of on the device")
     ap.add_argument("--reference-streams", action="store_true",
                     help="replay the reference's own random streams (seeds 679/347/124 consumed in its loop order, "
@@ -38,27 +40,31 @@ def main():
         torch.cuda.set_device(local)
         dist.init_process_group("nccl")
         device = torch.device("cuda", local)
-    mpc, model = common.make_mpc("cartpole", args.N, True, extended=args.extended, create=True, device=local)
+    # controller set up in the package: offline sets through the batched LP kernel on this rank's device (0.2 s)
+    mpc, model = workloads.make_controller("cartpole", args.N, True, extended=args.extended, device=local, tracking=args.rmpc)
     p_loss = np.arange(10) / 10.0                              # :149
     t0 = time.time()
     if args.reference_streams:
         if world != 1:
             raise SystemExit("--reference-streams keeps the reference's draw order and cannot be sharded")
         pl, th, ga, wd = montecarlo.draw_realisations_reference_order(p_loss, args.n_mc, args.T, model["w_bound"])
-        out = mpc.run_closed_loop(pl, np.full(args.T, args.ref), th, ga, wd, extended=args.extended)
+        out = mpc.run_closed_loop(pl, np.full(args.T, args.ref), th, ga, wd, extended=args.extended, warm_start=args.warm_start)
         table = np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]]
         pi = np.repeat(np.arange(len(p_loss)), args.n_mc)
     else:
         table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
-                                        extended=args.extended, device=device, on_device=not args.host_loop)
+                                        extended=args.extended, device=device, on_device=not args.host_loop, warm_start=args.warm_start)
     dt = time.time() - t0
     if rank == 0:
         n = len(pi)
         print(f"{n} trajectories x {args.T} steps = {n * args.T} solves in {dt:.2f} s on {world} GPU(s): {n * args.T / dt:.3e} MPC steps/s (end to end)")
-        print("p_loss  mean tracking error   tube violations   non-optimal solves")
+        print("p_loss  mean tracking error   tube violations   non-optimal solves   infeasible runs")
         for i, p in enumerate(p_loss):
             m = pi == i
-            print(f"{p:5.1f}   {table[m, 0].mean():.6f}            {int(table[m, 1].sum()):6d}            {int(table[m, 2].sum()):6d}")
+            te = table[m, 0]
+            dead = int(np.isnan(te).sum())                       # R-MPC: a run whose QP became infeasible stops (NaN tracking error, :297)
+            mean_te = float(np.nanmean(te)) if dead < m.sum() else float("nan")
+            print(f"{p:5.1f}   {mean_te:.6f}            {int(table[m, 1].sum()):6d}            {int(table[m, 2].sum()):6d}            {dead:6d}")
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -176,6 +176,36 @@ def test_device_pointer_entry_with_torch(cartpole, hip_lib):
     assert np.array_equal(st.cpu().numpy(), host["status"])
 
 
+def test_variant_ids_without_a_problem_are_flagged(cartpole, hip_lib):
+    """include/tmpc.h: on the device-pointer entry an instance whose variant id names no problem of the handle comes back with
+    status NUMERICAL and NaN outputs (no kernel solves it), its neighbours are unaffected; the host-pointer entry refuses the
+    call."""
+    import torch
+    mpc, _, _ = cartpole
+    h = mpc._handle
+    X, R = S[:8, :4].copy(), S[:8, 4:].copy()
+    var = np.zeros(8, np.uint8)
+    var[[2, 5]] = [1, 7]                              # the plain controller has one problem (variant 0)
+    base = mpc._solve(X, R, want_traj=False)
+    with pytest.raises(RuntimeError):
+        mpc._solve(X, R, var)
+    dev = torch.device("cuda:0")
+    x, r, v = (torch.from_numpy(a).to(dev) for a in (X, R, var))
+    u = torch.zeros((8, 10, 1), dtype=torch.float64, device=dev)
+    x0 = torch.zeros((8, 4), dtype=torch.float64, device=dev)
+    ss = torch.zeros((8, 5), dtype=torch.float64, device=dev)
+    st = torch.zeros(8, dtype=torch.int32, device=dev)
+    it = torch.zeros(8, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    hip_lib.solve_batch_device(h, 8, x.data_ptr(), r.data_ptr(), v.data_ptr(), u.data_ptr(), x0.data_ptr(), ss.data_ptr(), None,
+                               st.data_ptr(), it.data_ptr())
+    hip_lib.synchronize(h)
+    un, stn = u.cpu().numpy(), st.cpu().numpy()
+    assert list(stn[[2, 5]]) == [3, 3] and np.all(np.isnan(un[[2, 5]])) and np.all(np.isnan(ss.cpu().numpy()[[2, 5]]))
+    keep = [0, 1, 3, 4, 6, 7]
+    assert np.array_equal(un[keep], base["u_nom"][keep]) and np.all(stn[keep] == 0)
+
+
 def test_reference_horizon_N20(hip_lib, oracle_lib):
     """The horizon the reference's cartpole scripts use (results_linear_system.py:64, N = 20):
     nv = 21, 184 dense rows + the 420-row terminal block in factored form."""

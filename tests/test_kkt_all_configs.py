@@ -91,13 +91,15 @@ def test_cartpole_base_problem(hip_lib, N):
     n_opt, n_inf = certify(mpc, X, R, min_optimal=256)
 
 
-@pytest.mark.parametrize("N", [10, 20])
-def test_extended_packet_received_problem(hip_lib, N):
+@pytest.mark.parametrize("N,path", [(10, "auto"), (20, "auto"), (20, "block")])
+def test_extended_packet_received_problem(hip_lib, N, path):
     """BASELINE config 3: the gamma = 1 problem (TubeTrackingMPC.py:253-299) in its projected form, mixed with
     gamma = 0 instances in one call; plus the literal line :293 -- for the returned x_bar there must exist free
     auxiliaries (x_aux, u_aux) with HT [x_aux; x_bar; u_aux] <= hT."""
     from scipy.optimize import linprog
     mpc, w = common.make_mpc("cartpole", N, True, extended=True, create=True)
+    mpc.set_kernel_path(path)              # "block": the workgroup-per-QP kernel on the same instances (1056 rows, degenerate vertices)
+    assert mpc.get_kernel_path(1) == ("wave" if path == "auto" else "block")
     p = mpc._problem_dict()
     HT, hT = np.asarray(p["HT"]), np.asarray(p["hT"])
     nx, nu = 4, 1

@@ -80,3 +80,28 @@ def test_rmpc_closed_loop_device_equals_host(hip_lib):
     assert np.array_equal(dev["not_optimal"], host["not_optimal"])
     np.testing.assert_allclose(dev["tracking_error"][~dead], host["tracking_error"][~dead], atol=1e-10, rtol=0)
     np.testing.assert_allclose(dev["x_final"], host["x_final"], atol=1e-8, rtol=0)
+
+
+@pytest.mark.gpu
+def test_rmpc_cartpole_closed_loop_device_equals_host(hip_lib):
+    """The R-MPC leg of the reference's cartpole experiment (results_linear_system.py:132-140, 198-205, 262-287): TrackingMPC with
+    the UN-tightened cartpole sets, N = 20, over the lossy network with disturbances; device-resident loop against the numpy state
+    machines around the same device solver, incl. the trajectories that become infeasible (track_feasible = False, :268-270)."""
+    from LinearMPCOverNetworks import montecarlo
+    mpc, w = workloads.make_controller("cartpole", 20, tracking=True)
+    assert mpc._Xc is mpc._X and mpc.get_kernel_path() == "wave"
+    nb, T = 120, 120
+    p_loss = np.repeat(np.arange(10) / 10.0, nb // 10)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=17)
+    ref = np.where(np.arange(T) < 60, 0.5, -0.5)
+    host = montecarlo.run_remote_tracking_mpc(mpc.determine_packets, w["A"], w["B"], mpc.get_steady_state_controller_gain(), 20,
+                                              p_loss, ref, th, ga, dist)
+    dev = mpc.run_closed_loop(p_loss, ref, th, ga, dist)
+    dead = np.isnan(dev["tracking_error"])
+    assert np.array_equal(dead, host["infeasible"])
+    assert np.array_equal(dev["not_optimal"], host["not_optimal"])
+    np.testing.assert_allclose(dev["tracking_error"][~dead], host["tracking_error"][~dead], atol=1e-10, rtol=0)
+    np.testing.assert_allclose(dev["x_final"][~dead], host["x_final"][~dead], atol=1e-8, rtol=0)
+    assert (~dead).sum() >= nb // 2
+    lossless = (p_loss == 0.0) & ~dead
+    assert lossless.any() and np.all(np.abs(dev["x_final"][lossless][:, 0] + 0.5) < 0.3)               # loss-free runs are on their way to -0.5
