@@ -141,6 +141,11 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         found = tmpc::pick_config(c.nv, static_cast<int>(dpair.size()), static_cast<int>(dsing.size()), use_fact ? c.kc : 0,
                                   static_cast<int>(cpair.size()), static_cast<int>(csing.size()), &v.shape);
     }
+    if (found) {
+        // the dense functionals in use must fit the LDS next to the workspaces of the shape's waves
+        const int last = dsing.empty() ? static_cast<int>(dpair.size()) : v.shape.dp * 64 + static_cast<int>(dsing.size());
+        if (tmpc::lds_bytes(v.shape, 4 * ((last + 3) / 4)) > 160 * 1024) found = false;
+    }
     if (!found) return TMPC_OK;                                  // wave_ok stays false: the block kernel takes the variant
     const int NVP = v.shape.nvp, DP = v.shape.dp, DS = v.shape.ds, KCP = v.shape.kcp, CP = v.shape.cp, CS = v.shape.cs;
     const int NDP = (DP + DS) * 64, NCCP = (CP + CS) * 64, RS = 2 * DP + DS + 2 * CP + CS;

@@ -64,7 +64,7 @@ struct KernelShape {
 // Chooses the cheapest compiled shape that covers a variant with nd2 / nd1 dense paired / single functionals and nc2 / nc1
 // factored ones of width kc; false if none does.
 bool pick_config(int nv, int nd2, int nd1, int kc, int nc2, int nc1, KernelShape *shape);
-size_t lds_bytes(const KernelShape &shape);
+size_t lds_bytes(const KernelShape &shape, int grows);      // grows = 4 * nks rows of dense functionals staged in LDS
 const char *kernel_name(const KernelShape &shape);
 
 // Work counters of the wave kernel's persistent grid: every launch draws its instances from a fresh, zeroed device word of

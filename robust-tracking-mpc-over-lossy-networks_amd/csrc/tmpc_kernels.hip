@@ -142,6 +142,9 @@ template <> struct Blocks<16> { static constexpr int n = 4; static constexpr int
 template <> struct Blocks<24> { static constexpr int n = 8; static constexpr int b[9] = {0, 1, 3, 5, 7, 10, 13, 17, 24}; };
 template <> struct Blocks<28> { static constexpr int n = 10; static constexpr int b[11] = {0, 1, 3, 5, 7, 9, 11, 14, 17, 21, 28}; };
 
+// entries per round of the transposition tile: 12 where the LDS is short (two waves per SIMD; the NV = 28 shape), else 16
+constexpr int tile_rows(int nv, int wpb) { return (wpb == 8 || nv > 24) ? 12 : 16; }
+
 // compile-time description of one kernel instantiation
 template <int NV_, int DP_, int DS_, int KC_, int CP_, int CS_, int RR_>
 struct Shape {
@@ -151,7 +154,7 @@ struct Shape {
     static constexpr int NDP = FD * WAVE, NCCP = FC * WAVE;
     static constexpr int RS = 2 * DP_ + DS_ + 2 * CP_ + CS_;      // row sides per lane
     static constexpr int NT = NV_ * (NV_ + 1) / 2, KT = KC_ * (KC_ + 1) / 2;
-    static constexpr int WCAP = NV_ <= 24 ? 24 : WS_CAP;          // max rows in the refinement's working set
+    static constexpr int WCAP = NV_ <= 24 ? 24 : 28;              // max rows in the refinement's working set (<= WS_CAP)
     // dense functionals, row-major in LDS: [FD * 64][LDG]; 16-column blocks of the MFMA tiling cover the NV columns of G
     // plus one more row of the product (row NV of A carries t: see sweep_a_dense); the odd stride keeps both the
     // lane-per-row reads of the sweeps and the 4 x 16 operand reads of the MFMA loop conflict free
@@ -185,12 +188,12 @@ struct WaveLds {
     static constexpr int MFAC = SH::NV * (SH::NV + 1);                                  // factor of the normal matrix between the two solves (row i at i (NV + 1), then 1 / d_i)
     static constexpr int BIG = RED + MFAC > POL ? RED + MFAC : POL;                     // tile + factor (interior point) and the refinement's workspace are never live together
     static constexpr int SUMS = 2 * SH::NV + 8;                                         // two NV-vectors of G' products
-    static constexpr int DTW = 2 * SH::NDP;                                             // (D, t) per dense functional for the MFMA pass
     static constexpr int CSUMS = SH::KT + 2 * SH::KC + 8;                               // factored-block totals
     static constexpr int PMAT = SH::KCA * SH::NV;                                       // W * Psi
     static constexpr int HROW = SH::RS * WAVE;                                          // right-hand side h, [side][lane]
     static constexpr int VEC = 9 * SH::NV + 32;                                         // q, z, cost gradient, x_k, ref, scratch, dz_aff, dz, Psi-coordinates
-    static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC + DTW;
+    static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC;
+    static_assert(RED >= 2 * SH::NDP, "(D, t) of the dense functionals share the transposition tile");
 };
 
 // out = Psi vec for vectors kept in LDS: lane a < KC forms entry a (broadcast reads of vec)
@@ -207,8 +210,8 @@ __device__ __forceinline__ void coords_lds(const double *Psi, const double *vec,
 
 // g . v for this lane's dense functional of slot KD / factored functional of slot KCS; v (and c = Psi v) in LDS
 template <class SH, int KD>
-__device__ __forceinline__ double dense_dot(const double *Gt, const double *v, int lane) {
-    const double *g = Gt + (lane + KD * WAVE) * SH::LDG;
+__device__ __forceinline__ double dense_dot(const double *Gt, int grows, const double *v, int lane) {
+    const double *g = Gt + min(lane + KD * WAVE, grows) * SH::LDG;      // functionals beyond the staged rows read the zero row
     double t0 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int j = 0; j + 1 < SH::NV; j += 2) { t0 += g[j] * v[j]; t1 += g[j + 1] * v[j + 1]; }
@@ -343,16 +346,17 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters,
     const int32_t *__restrict__ ws_in, int32_t *__restrict__ ws_out, unsigned long long *__restrict__ next_item) {
-    using SH = Shape<NV, DP, DS, KC, CP, CS, (WPB == 8 ? 12 : 16)>;
+    using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
     using WL = WaveLds<SH>;
     constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, KT = SH::KT, WCAP = SH::WCAP, LDG = SH::LDG;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    double *Gt = smem;                         // [NDP][LDG]  dense functionals, row-major (odd stride)
-    double *Hct = Gt + NDP * LDG;              // [KC][NCCP]
+    double *wbase = smem;                      // WPB per-wave workspaces
+    double *Hct = wbase + WPB * WL::TOTAL;     // [KC][NCCP]
     double *Psi = Hct + KC * NCCP;             // [KC][NV]
     double *Hs = Psi + KC * NV;                // [NV][NV]
     double *Hinv = Hs + NV * NV;               // [NV][NV]
-    double *wbase = Hinv + NV * NV;
+    double *Gt = Hinv + NV * NV;               // [grows + 1][LDG]  dense functionals in use, row-major (odd stride), then a zero row
+    const int grows = 4 * qp.nks;              // (last in the layout: its size is the only one that depends on the problem)
 
     const int tid = threadIdx.x;
     const int lane_k = tid & (WAVE - 1);
@@ -361,7 +365,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nc = qp.nc;
 
     // ---- stage the shared model once per workgroup (coalesced, L2-resident source)
-    for (int i = tid; i < NDP * LDG; i += blockDim.x) Gt[i] = qp.Gt[i];
+    for (int i = tid; i < (grows + 1) * LDG; i += blockDim.x) Gt[i] = (i < grows * LDG) ? qp.Gt[i] : 0.0;
     for (int i = tid; i < KC * NCCP; i += blockDim.x) Hct[i] = qp.Hct[i];
     for (int i = tid; i < KC * NV; i += blockDim.x) Psi[i] = qp.Psi[i];
     for (int i = tid; i < NV * NV; i += blockDim.x) { Hs[i] = qp.Hs[i]; Hinv[i] = qp.Hinv[i]; }
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *Pm = csums + WL::CSUMS;               // [KC][NV] W * Psi
     double *hw = Pm + WL::PMAT;                   // h, [side][lane]
     double *vec = hw + WL::HROW;
-    double *dtw = vec + WL::VEC;      // [NDP][2] (D, t) of the dense functionals (MFMA pass of sweep A)
+    double *dtw = red;                // [NDP][2] (D, t) of the dense functionals during the MFMA pass of sweep A (the tile is idle then)
     double *Mf = red + WL::RED;       // [NV][NV + 1]  normal matrix, then its factor (behind the transposition tile, inside the refinement's idle workspace)
     double *qv = vec;                 // [NV] linear term
     double *zv = vec + NV;            // [NV] current z (wave-uniform copy)
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             double smin = INFINITY;
             static_for<FD>([&](auto kd_) {
                 constexpr int kd = decltype(kd_)::value;
-                const double gz = dense_dot<SH, kd>(Gt, zv, lane);
+                const double gz = dense_dot<SH, kd>(Gt, grows, zv, lane);
 #pragma unroll
                 for (int sd = 0; sd < SH::dsides(kd); ++sd) {
                     const int i = SH::dbase(kd) + sd;
@@ -633,7 +637,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             for (int i = 0; i < NV; ++i) accl[i] = 0.0;
                             static_for<FD>([&](auto kd_) {
                                 constexpr int kd = decltype(kd_)::value;
-                                const int r = lane + kd * WAVE;
+                                const int r = min(lane + kd * WAVE, grows);
                                 double dl2 = lam[SH::dbase(kd)];
                                 if constexpr (SH::dsides(kd) == 2) dl2 -= lam[SH::dbase(kd) + 1];
 #pragma unroll
@@ -774,7 +778,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             double accb[2 * NV];
                             static_for<FD>([&](auto kd_) {
                                 constexpr int kd = decltype(kd_)::value;
-                                const int r = lane + kd * WAVE;
+                                const int r = min(lane + kd * WAVE, grows);
                                 double g[NV];
                                 double gd0 = 0.0, gd1 = 0.0;
 #pragma unroll
@@ -865,7 +869,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         };
                         static_for<FD>([&](auto kd_) {
                             constexpr int kd = decltype(kd_)::value;
-                            const double gdz = dense_dot<SH, kd>(Gt, dzv, lane);
+                            const double gdz = dense_dot<SH, kd>(Gt, grows, dzv, lane);
 #pragma unroll
                             for (int sd = 0; sd < SH::dsides(kd); ++sd) side_step(SH::dbase(kd) + sd, sd == 1, gdz);
                             row_fence();
@@ -1099,7 +1103,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         };
                         static_for<FD>([&](auto kd_) {
                             constexpr int kd = decltype(kd_)::value;
-                            const double gz = dense_dot<SH, kd>(Gt, zpv, lane);
+                            const double gz = dense_dot<SH, kd>(Gt, grows, zpv, lane);
 #pragma unroll
                             for (int sd = 0; sd < SH::dsides(kd); ++sd) check_side(SH::dbase(kd) + sd, sd ? -gz : gz);
                         });
@@ -1205,21 +1209,24 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     }
 }
 
+// LDS of a workgroup: per-wave workspaces, the shared model, and `grows` (+ 1 zero) rows of the dense functionals
 template <class SH>
-constexpr size_t kernel_lds_bytes(int wpb) {
-    return sizeof(double) * (static_cast<size_t>(SH::LDG) * SH::NDP + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
+constexpr size_t kernel_lds_bytes(int wpb, int grows) {
+    return sizeof(double) * (static_cast<size_t>(SH::LDG) * (grows + 1) + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
                              static_cast<size_t>(wpb) * WaveLds<SH>::TOTAL);
 }
-// Waves per workgroup = waves per CU (one persistent workgroup per CU).  Eight (two per SIMD: at most 256 registers each,
-// smaller transposition tile) for the small shapes, whose live set fits; four (one per SIMD, the accumulation-register file
-// as spill space) otherwise, fewer if the LDS does not hold four workspaces.
+// rows of dense functionals the shapes are sized for: one slot in full, 96 of the 128 of two slots (cartpole N = 20: 92 / 93)
+template <int DP, int DS>
+constexpr int design_rows() { return (DP + DS) * WAVE <= 64 ? (DP + DS) * WAVE : ((DP + DS) * WAVE * 3) / 4; }
+// Waves per workgroup = waves per CU (one persistent workgroup per CU).  Eight (two per SIMD: at most 256 registers each)
+// for the small shapes, whose live set fits; four (one per SIMD, the accumulation-register file as spill space) otherwise,
+// fewer if the LDS does not hold four workspaces.
 template <int NV, int DP, int DS, int KC, int CP, int CS>
 constexpr int waves_per_block() {
-#ifndef TMPC_NO8
-    if (NV <= 12 && kernel_lds_bytes<Shape<NV, DP, DS, KC, CP, CS, 12>>(8) <= 160 * 1024) return 8;
-#endif
-    using SH = Shape<NV, DP, DS, KC, CP, CS, 16>;
-    return kernel_lds_bytes<SH>(4) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3) <= 160 * 1024 ? 3 : 2);
+    constexpr int gr = design_rows<DP, DS>();
+    if (NV <= 12 && kernel_lds_bytes<Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, 8)>>(8, gr) <= 160 * 1024) return 8;
+    using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, 4)>;
+    return kernel_lds_bytes<SH>(4, gr) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3, gr) <= 160 * 1024 ? 3 : 2);
 }
 
 template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
@@ -1227,9 +1234,9 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, WorkCounter *wc, int n_cu,
                       hipStream_t stream) {
-    using SH = Shape<NV, DP, DS, KC, CP, CS, (WPB == 8 ? 12 : 16)>;
-    constexpr size_t lds = kernel_lds_bytes<SH>(WPB);
-    static_assert(lds <= 160 * 1024, "shape does not fit the 160 KiB LDS of a CU");
+    using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
+    const size_t lds = kernel_lds_bytes<SH>(WPB, 4 * qp.nks);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;       // (tmpc_api.cpp checks lds_bytes() before it accepts the wave path)
     static_assert(SH::RS <= 32, "validity mask is one 32-bit word per lane");
     // > 64 KiB of dynamic LDS needs the opt-in once per device and instantiation
     static bool attr_set[64] = {};
@@ -1275,11 +1282,11 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     X(12, 1, 0, 5, 4, 0) X(24, 2, 0, 5, 4, 0) X(16, 1, 0, 4, 7, 0) X(28, 2, 0, 4, 7, 0)
 #endif
 
-size_t lds_bytes(const KernelShape &s) {
+size_t lds_bytes(const KernelShape &s, int grows) {
 #define TMPC_LDS(A, B_, C, D, E, F) \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F) { \
         constexpr int wpb = waves_per_block<A, B_, C, D, E, F>(); \
-        return kernel_lds_bytes<Shape<A, B_, C, D, E, F, (wpb == 8 ? 12 : 16)>>(wpb); }
+        return kernel_lds_bytes<Shape<A, B_, C, D, E, F, tile_rows(A, wpb)>>(wpb, grows); }
     TMPC_SHAPES(TMPC_LDS)
 #undef TMPC_LDS
     return 0;
