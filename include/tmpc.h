@@ -219,6 +219,16 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
 int tmpc_mc_set_warm_start(tmpc_handle *h, int on);
 
 /*
+ * Sample trajectory of tmpc_mc_run -- what the scripts keep for their plots (x_traj, x_nom_traj of one run per loss rate,
+ * results_linear_system.py:298-301).  tmpc_mc_set_capture(index >= 0) makes the following runs record trajectory `index`
+ * (-1: off); after a run tmpc_mc_get_capture copies out, for t = 0 .. T-1, the plant state x_t, the nominal state the tube
+ * check of step t uses, and the applied input u_t (row-major T x nx, T x nx, T x nu; any pointer may be NULL).  Dead
+ * trajectories of the R-MPC loop leave zeros from their last step on.
+ */
+int tmpc_mc_set_capture(tmpc_handle *h, int64_t index);
+int tmpc_mc_get_capture(tmpc_handle *h, int32_t T, double *x_traj, double *x_nom_traj, double *u_traj);
+
+/*
  * Plant simulated by tmpc_mc_run.  TMPC_PLANT_LINEAR (default): x+ = A x + B u + w (results_linear_system.py:248).
  * TMPC_PLANT_CARTPOLE: the nonlinear cart-pole the linear model was derived from (results_linear_system.py:26-47;
  * the reference integrates it with PyBullet at 500 Hz, results_nonlinear_system.py:30-37), zero-order hold of the

@@ -211,18 +211,20 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         U = np.concatenate([out["u_nom"], u_ss[:, None, :]], axis=1)     # (B, N+1, nu)
         return np.ascontiguousarray(U.transpose(0, 2, 1)), out["x_nom0"], out["status"]
 
-    def run_closed_loop(self, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False, plant=None, warm_start: bool = False) -> dict:
+    def run_closed_loop(self, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False, plant=None, warm_start: bool = False,
+                        capture=None) -> dict:
         """The lossy-network closed loop of the reference's Monte-Carlo scripts (results_linear_system.py:209-291)
         for a batch of trajectories, resident on the device (include/tmpc.h: tmpc_mc_run): every time step is one
         solve launch plus one state-machine launch, nothing returns to the host in between.  warm_start: every solve first
-        tries the working set of the trajectory's previous solve in the exact refinement (same results, fewer iterations)."""
+        tries the working set of the trajectory's previous solve in the exact refinement (same results, fewer iterations);
+        capture: index of one trajectory whose x_t / x_nom_t / u_t are returned (the scripts' sample run, :298-301)."""
         from . import _native
         if self._handle is None:
             raise RuntimeError("setup_optimization() has not been called")
         _native.mc_set_plant(self._handle, plant)        # None: the linear model; 'cartpole': the nonlinear cart-pole (RK4, 500 Hz)
         _native.mc_set_actuator(self._handle, self._smart_actuator)
         return _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
-                              extended=extended, warm_start=warm_start)
+                              extended=extended, warm_start=warm_start, capture=capture)
 
     # ------------------------------------------------------------------ accessors
     def set_ancillary_controller_gain(self, K_ancillary):

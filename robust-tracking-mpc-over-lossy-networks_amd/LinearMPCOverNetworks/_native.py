@@ -88,6 +88,10 @@ def lib():
         L.tmpc_kernel_name.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_kernel_name.restype = C.c_char_p
         L.tmpc_mc_run.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8 + [C.c_int32] + [C.c_void_p] * 6
+        L.tmpc_mc_set_capture.argtypes = [C.c_void_p, C.c_int64]
+        L.tmpc_mc_set_capture.restype = C.c_int
+        L.tmpc_mc_get_capture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.tmpc_mc_get_capture.restype = C.c_int
         L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_warm_start.restype = C.c_int
         L.tmpc_mc_run.restype = C.c_int
@@ -287,10 +291,14 @@ def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
         raise RuntimeError(h.error())
 
 
-def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False) -> dict:
+def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False,
+           capture=None) -> dict:
     """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device.
-    warm_start: tmpc_mc_set_warm_start for this call."""
+    warm_start: tmpc_mc_set_warm_start for this call; capture: index of a trajectory to record (tmpc_mc_set_capture) ->
+    x_traj (T, nx), x_nom_traj (T, nx), u_traj (T, nu) in the result."""
     if lib().tmpc_mc_set_warm_start(h.ptr, int(bool(warm_start))) != 0:
+        raise RuntimeError(h.error())
+    if lib().tmpc_mc_set_capture(h.ptr, -1 if capture is None else int(capture)) != 0:
         raise RuntimeError(h.error())
     c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
     th_u, ga_u, w, p_loss, ref = c(th_u), c(ga_u), c(w), c(p_loss), c(ref)
@@ -311,6 +319,10 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
                            ptr(out["x_final"]), ptr(out["consistent"]), ptr(out["iters_sum"]))
     if rc != 0:
         raise RuntimeError(f"tmpc_mc_run failed ({rc}): {h.error()}")
+    if capture is not None:
+        out["x_traj"], out["x_nom_traj"], out["u_traj"] = np.empty((T, h.nx)), np.empty((T, h.nx)), np.empty((T, h.nu))
+        if lib().tmpc_mc_get_capture(h.ptr, T, ptr(out["x_traj"]), ptr(out["x_nom_traj"]), ptr(out["u_traj"])) != 0:
+            raise RuntimeError(h.error())
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
     out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve

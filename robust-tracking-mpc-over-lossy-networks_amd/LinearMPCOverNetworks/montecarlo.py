@@ -88,7 +88,7 @@ def draw_realisations_reference_order(p_loss, n_mc: int, T: int, w_bound, seeds=
 
 
 def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False,
-                        plant=None):
+                        plant=None, capture=None):
     """Closed loop of the remote tube-based MPC over a lossy network for a batch of trajectories:
     the body of the reference's Monte-Carlo loop (results_linear_system.py:209-259, 291) with the
     per-trajectory objects replaced by the batched state machines and the QP solves of one time
@@ -102,6 +102,8 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     p_loss (B,), ref (T,) or (B,T) position reference, th_u/ga_u (B,T) uniforms, w (B,T,nx) disturbances.
     plant: None = the linear model x+ = A x + B u + w (:248); or a callable (x (B,nx), u (B,nu)) -> x+ (w is added to it),
     e.g. workloads.cartpole_step for the nonlinear cart-pole of results_nonlinear_system.py.
+    capture: index of one trajectory whose x_t, nominal state of the tube check and u_t are recorded (the scripts' sample run,
+    :298-301) -> 'x_traj' (T, nx), 'x_nom_traj' (T, nx), 'u_traj' (T, nu).
     Returns a dict of per-trajectory statistics."""
     from .Estimator import BatchedEstimator
     from .SmartActuator import BatchedConsistentActuator
@@ -115,6 +117,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     def ref_at(t):
         return ref[t] if ref.ndim == 1 else ref[:, t]
     x = np.zeros((nb, nx)) if x0 is None else np.array(x0, dtype=np.float64).reshape(nb, nx)
+    cap = None if capture is None else dict(x_traj=np.zeros((T, nx)), x_nom_traj=np.zeros((T, nx)), u_traj=np.zeros((T, Bm.shape[1])))
     est = BatchedEstimator(A, Bm, K, x, N, K_plant=K_plant if extended else None, robust=extended)
     act = BatchedConsistentActuator(A, Bm, K, K_plant, x, is_extended_MPC_used=extended)
     err2 = np.zeros(nb)
@@ -151,6 +154,8 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
         # appended after the PREVIOUS step's process_packet, so for the extended controller the state before this step's
         # adoption of x_nom_0 (SmartActuator.py:219-222); for the plain tube MPC the two coincide
         tube_viol += ~np.asarray(Z.contains((x - x_nom_now).T)).reshape(nb)
+        if cap is not None:
+            cap["x_traj"][t], cap["x_nom_traj"][t], cap["u_traj"][t] = x[capture], x_nom_now[capture], u[capture]
         x = (x @ A.T + u @ Bm.T if plant is None else plant(x, u)) + w[:, t]                      # :248
         gamma = np.where(ga_u[:, t] < p_loss, 0, 1) if t > 0 else np.ones(nb, dtype=np.int64)     # :218-226
         est.update(pkt, gamma)                                                                     # :254
@@ -159,8 +164,11 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
         ok = (act.Theta == 1) & (gamma == 1)
         if ok.any():
             consistent_err = max(consistent_err, float(np.max(np.abs(est.x_hat[ok] - act.x_nom[ok]))))
-    return dict(tracking_error=np.sqrt(err2) / T, tube_violations=tube_viol, not_optimal=not_optimal,
-                consistent_estimate_error=consistent_err, x_final=x)
+    out = dict(tracking_error=np.sqrt(err2) / T, tube_violations=tube_viol, not_optimal=not_optimal,
+               consistent_estimate_error=consistent_err, x_final=x)
+    if cap is not None:
+        out.update(cap)
+    return out
 
 
 def run_remote_tracking_mpc(packets_fn, A, B, K, N, p_loss, ref, th_u, ga_u, w, x0=None):

@@ -51,6 +51,9 @@ struct tmpc_handle {
     int plant = TMPC_PLANT_LINEAR, plant_substeps = 10;
     int actuator = TMPC_ACTUATOR_CONSISTENT;
     tmpc::WorkCounter wc;        // work counters of the wave kernel's launches (tmpc_device.hpp)
+    long long mc_capture = -1;   // trajectory recorded by the next tmpc_mc_run (-1: none)
+    double *mc_cap_dev = nullptr; // its record in the arena: [mc_cap_T][2 nx + nu]
+    int mc_cap_T = 0;
     int mc_warm = 0;             // closed loop: hand every solve the working set of the trajectory's previous solve of the same variant
     double plant_par[7] = {0, 0, 0, 0, 0, 0, 0};
     int kernel_path = TMPC_PATH_AUTO;
@@ -568,6 +571,29 @@ int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps
     return TMPC_OK;
 }
 
+int tmpc_mc_set_capture(tmpc_handle *h, int64_t index) {
+    if (!h) return TMPC_E_INVALID;
+    h->mc_capture = index < 0 ? -1 : index;
+    return TMPC_OK;
+}
+
+int tmpc_mc_get_capture(tmpc_handle *h, int32_t T, double *x_traj, double *x_nom_traj, double *u_traj) {
+    if (!h) return TMPC_E_INVALID;
+    if (!h->mc_cap_dev || T != h->mc_cap_T) { h->err = "tmpc_mc_get_capture: no trajectory of this length was recorded by the last tmpc_mc_run"; return TMPC_E_INVALID; }
+    const size_t nx = h->nx, nu = h->nu, w = 2 * nx + nu;
+    std::vector<double> buf(static_cast<size_t>(T) * w);
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipMemcpy(buf.data(), h->mc_cap_dev, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int t = 0; t < T; ++t) {
+        for (size_t i = 0; i < nx; ++i) {
+            if (x_traj) x_traj[t * nx + i] = buf[t * w + i];
+            if (x_nom_traj) x_nom_traj[t * nx + i] = buf[t * w + nx + i];
+        }
+        for (size_t j = 0; j < nu; ++j) if (u_traj) u_traj[t * nu + j] = buf[t * w + 2 * nx + j];
+    }
+    return TMPC_OK;
+}
+
 int tmpc_mc_set_warm_start(tmpc_handle *h, int on) {
     if (!h) return TMPC_E_INVALID;
     h->mc_warm = on ? 1 : 0;
@@ -591,7 +617,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
     const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + 2 * t_ + t_ * nx)) +
-                        8 * b * (6 * nx + (N + 1) * nu + nu + 2) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE;
+                        8 * b * (6 * nx + (N + 1) * nu + nu + 2) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
     if (need > h->mc_arena_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mc_arena) (void)hipFree(h->mc_arena);
@@ -653,6 +679,16 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             HIP_TRY(h, hipMemcpyAsync(st.x, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipMemcpyAsync(st.x_hat, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
             HIP_TRY(h, hipMemcpyAsync(st.x_nom, x0, b * nx * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        st.cap_index = -1;
+        st.cap = nullptr;
+        h->mc_cap_dev = nullptr;
+        if (h->mc_capture >= 0 && h->mc_capture < B) {
+            if ((r2 = dalloc(t_ * (2 * nx + nu) * 8, reinterpret_cast<void **>(&st.cap)))) return r2;
+            HIP_TRY(h, hipMemsetAsync(st.cap, 0, t_ * (2 * nx + nu) * 8, h->stream));
+            st.cap_index = h->mc_capture;
+            h->mc_cap_dev = st.cap;
+            h->mc_cap_T = T;
         }
         // warm start: one working-set record per trajectory and variant (row ids are per variant), updated in place by the
         // solve kernel; m = 0 (the memset) means "nothing to start from"

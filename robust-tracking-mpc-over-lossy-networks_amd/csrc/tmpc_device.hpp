@@ -110,6 +110,8 @@ struct McState {                         // all [trajectory]-major device arrays
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
     uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
+    long long cap_index;                      // trajectory whose states are recorded (-1: none)
+    double *cap;                              // [T][2 nx + nu]: x_t, the nominal state the tube check uses, u_t
 };
 hipError_t launch_mark_invalid_variants(const uint8_t *variant, int nvariants, int64_t B, int nx, int nu, int N, double *u_nom,
                                         double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters,

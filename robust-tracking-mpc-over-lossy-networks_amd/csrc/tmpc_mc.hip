@@ -110,6 +110,12 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
         for (int i = 0; i < nx; ++i) w2 -= m.K_anc[j * nx + i] * e[i];
         u[j] = w2;
     }
+    if (b == st.cap_index) {
+        // sample run of the scripts (results_linear_system.py:298-301: x_traj, x_nom_traj of one run per loss rate)
+        double *c = st.cap + static_cast<size_t>(t) * (2 * nx + nu);
+        for (int i = 0; i < nx; ++i) { c[i] = x[i]; c[nx + i] = x[i] - st.e_buf[b * nx + i]; }
+        for (int j = 0; j < nu; ++j) c[2 * nx + j] = u[j];
+    }
     // ---- statistics (results_linear_system.py:258, 291)
     {
         double a = (x[0] - ref_t) * (x[0] - ref_t);

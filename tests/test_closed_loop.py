@@ -262,3 +262,27 @@ def test_nonlinear_plant_against_an_independent_integrator():
         ref = solve_ivp(rhs, (0.0, 0.02), x0, args=(F,), rtol=1e-12, atol=1e-14).y[:, -1]
         got = workloads.cartpole_step(x0, np.array(F))                  # RK4, 10 substeps of 2 ms (the reference's physics rate)
         np.testing.assert_allclose(got, ref, atol=2e-9, rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extended", [False, True])
+def test_sample_trajectory_capture(hip_lib, extended):
+    """tmpc_mc_set_capture / tmpc_mc_get_capture: the sample run the scripts keep for their plots (x_traj, x_nom_traj,
+    results_linear_system.py:298-301) from the device loop = the one recorded by the host loop; the recorded pair is what the
+    tube statistic tests."""
+    nb, T = 16, 90
+    mpc, w = common.make_mpc("cartpole", 10, True, extended=extended, create=True)
+    p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=3)
+    ref = np.where(np.arange(T) < 45, 0.5, -0.2)
+    k = min(5, nb - 1)                                                   # :298 l_mc == min(5, N_MC - 1)
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    host = montecarlo.run_remote_tube_mpc(mpc.determine_packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist,
+                                          extended=extended, capture=k)
+    dev = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended, capture=k)
+    for key in ("x_traj", "x_nom_traj", "u_traj"):
+        np.testing.assert_allclose(dev[key], host[key], atol=1e-8, rtol=0, err_msg=key)
+    assert np.all(mpc._Z.contains((dev["x_traj"] - dev["x_nom_traj"]).T, 1e-7))
+    np.testing.assert_allclose(dev["x_traj"][0], 0.0, atol=0)
+    again = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended)          # the setting is per call
+    assert "x_traj" not in again

@@ -150,8 +150,10 @@ def test_closed_loop_setters_validate_their_arguments(hip_lib):
     one = np.zeros((1, 1))
     rc = L.tmpc_mc_run(h.ptr, 1, 1, 0, one.ctypes.data, one.ctypes.data, one.ctypes.data, one.ctypes.data, np.zeros((1, 1, 4)).ctypes.data,
                        None, None, None, 0, None, None, None, None, None, None)
-    assert L.tmpc_mc_set_warm_start(h.ptr, 1) == 0 and L.tmpc_mc_set_warm_start(h.ptr, 0) == 0
     assert rc == -3 and b"GPU" in L.tmpc_last_error(h.ptr)                      # TMPC_E_DEVICE: no CPU path
+    assert L.tmpc_mc_set_warm_start(h.ptr, 1) == 0 and L.tmpc_mc_set_warm_start(h.ptr, 0) == 0
+    assert L.tmpc_mc_set_capture(h.ptr, 3) == 0 and L.tmpc_mc_set_capture(h.ptr, -1) == 0
+    assert L.tmpc_mc_get_capture(h.ptr, 5, None, None, None) == -1 and b"recorded" in L.tmpc_last_error(h.ptr)
     hip_lib.destroy(h)
     # double integrator: the cart-pole plant needs nx = 4, nu = 1
     mpc2, _ = common.make_mpc("double_integrator", 5, False)
