@@ -93,6 +93,9 @@ typedef struct tmpc_problem {
     const double *Hx, *hx, *Hu, *hu, *HT, *hT, *HZ, *hZ, *HZW, *hZW;
     const double *HTP, *hTP;    /* rTP x (nx+nu), rTP; may be NULL */
     int32_t rTP;
+    int32_t terminal_equality;  /* 1: x_N == x_bar instead of a terminal set (TrackingMPC.py:105-107: the tracking MPC
+                                 * before setup_optimization()); needs rT == 0.  The nx equalities are eliminated at set-up
+                                 * like the dynamics and the steady-state equation. */
 } tmpc_problem;
 
 typedef struct tmpc_handle tmpc_handle;

@@ -24,7 +24,7 @@ class Problem(C.Structure):
     _fields_ = ([(n, C.c_int32) for n in ("nx", "nu", "N", "rx", "ru", "rT", "rZ", "rZW",
                                           "fixed_x0", "extended", "literal_terminal_row", "max_iter")]
                 + [("tol", C.c_double)]
-                + [(n, C.POINTER(C.c_double)) for n in _PTR_FIELDS] + [("rTP", C.c_int32)])
+                + [(n, C.POINTER(C.c_double)) for n in _PTR_FIELDS] + [("rTP", C.c_int32), ("terminal_equality", C.c_int32)])
 
 
 def pack_problem(d: dict):
@@ -64,6 +64,7 @@ def pack_problem(d: dict):
     p.rT = rows("HT", 2 * nx + nu)
     p.rZ, p.rZW = rows("HZ", nx), rows("HZW", nx)
     p.rTP = rows("HTP", nx + nu)
+    p.terminal_equality = int(d.get("terminal_equality", 0))
     for hk, Hk in (("hx", "Hx"), ("hu", "Hu"), ("hT", "HT"), ("hZ", "HZ"), ("hZW", "HZW"), ("hTP", "HTP")):
         if d.get(Hk) is not None and np.asarray(d[hk]).size != np.asarray(d[Hk]).shape[0]:
             raise ValueError(f"{hk} / {Hk} row mismatch")

@@ -75,7 +75,9 @@ def build_sparse_qp(p: dict, x_k, ref, variant: int = 0):
     packet-received problem (needs p['HZW'], p['hZW'])."""
     nx, nu, N = int(p["nx"]), int(p["nu"]), int(p["N"])
     A, B, Q, R, Pm, T = (np.asarray(p[k], dtype=np.float64) for k in ("A", "B", "Q", "R", "P", "T"))
-    Hx, hx, Hu, hu, HT, hT = (np.asarray(p[k], dtype=np.float64) for k in ("Hx", "hx", "Hu", "hu", "HT", "hT"))
+    Hx, hx, Hu, hu = (np.asarray(p[k], dtype=np.float64) for k in ("Hx", "hx", "Hu", "hu"))
+    HT = np.asarray(p["HT"], dtype=np.float64) if p.get("HT") is not None else np.zeros((0, 2 * nx + nu))
+    hT = np.asarray(p["hT"], dtype=np.float64) if p.get("hT") is not None else np.zeros(0)
     x_k = np.asarray(x_k, dtype=np.float64).reshape(nx)
     ref = np.asarray(ref, dtype=np.float64).reshape(nx)
     received = variant == 1
@@ -125,6 +127,10 @@ def build_sparse_qp(p: dict, x_k, ref, variant: int = 0):
         h.append(hu)
     Aeq.append((A - np.eye(nx)) @ sel(L.xbar) + B @ sel(L.ubar))
     beq.append(np.zeros(nx))
+    if not received and int(p.get("terminal_equality", 0)):
+        # TrackingMPC.py:105-107: the tracking MPC without a terminal set constrains x_N == x_bar
+        Aeq.append(sel(L.x(N)) - sel(L.xbar))
+        beq.append(np.zeros(nx))
     if projected:
         HTP, hTP = np.asarray(p["HTP"], dtype=np.float64), np.asarray(p["hTP"], dtype=np.float64)
         G.append(HTP[:, :nx] @ sel(L.xbar) + HTP[:, nx:] @ sel(L.ubar))

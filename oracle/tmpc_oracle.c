@@ -157,7 +157,10 @@ static int build_sparse(const tmpc_problem *p, int variant, sparse_t *s) {
     const int rz = received ? p->rZW : (fixed ? 0 : p->rZ);
     const double *HZ = received ? p->HZW : p->HZ, *hZ = received ? p->hZW : p->hZ;
     if (rz > 0 && (!HZ || !hZ)) return -1;
-    const int me = (fixed ? nx : 0) + nx * N + nx;
+    /* TrackingMPC.py:105-107: without a terminal set the tracking MPC constrains x_N == x_bar */
+    const int term_eq = (!received) && p->terminal_equality;
+    if (term_eq && p->rT > 0) return -1;
+    const int me = (fixed ? nx : 0) + nx * N + nx + (term_eq ? nx : 0);
     const int mi = rz + N * (p->rx + p->ru) + (projected ? p->rTP : p->rT);
     s->nvar = nvar; s->me = me; s->mi = mi;
     s->P = dalloc((size_t)nvar * nvar); s->Qr = dalloc((size_t)nvar * nx);
@@ -222,6 +225,14 @@ static int build_sparse(const tmpc_problem *p, int variant, sparse_t *s) {
         for (int j = 0; j < nu; ++j) s->Aeq[(er + r) * nvar + oub + j] = p->B[r * nu + j];
     }
     er += nx;
+    if (term_eq) {
+        /* x_N - x_bar = 0 */
+        for (int r = 0; r < nx; ++r) {
+            s->Aeq[(er + r) * nvar + ox + N * nx + r] = 1.0;
+            s->Aeq[(er + r) * nvar + oxb + r] = -1.0;
+        }
+        er += nx;
+    }
     /* terminal */
     if (projected) {
         for (int r = 0; r < p->rTP; ++r) {

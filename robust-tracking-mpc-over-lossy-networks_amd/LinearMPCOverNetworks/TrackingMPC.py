@@ -8,8 +8,9 @@ packetisation of Pezzutto 2022): same constructor, `setup_optimization()`, `solv
 (:87), the UN-tightened sets X and U (:94-97) and the terminal set computed from them
 (:155-185): the same condensed form, the same kernels, different (H, h).
 
-Not supported: the equality terminal constraint x_N == x_bar used when no terminal set has been
-computed (TrackingMPC.py:105-107); every reference script calls `setup_optimization()` first.
+Without a terminal set (no `setup_optimization()` / `determine_Xf()` yet) the reference constrains x_N == x_bar
+(TrackingMPC.py:105-107); so does this class (`terminal_equality` of include/tmpc.h: the nx equalities are eliminated at
+set-up like the dynamics).
 """
 from __future__ import annotations
 
@@ -39,10 +40,20 @@ class TrackingMPC(TubeTrackingMPC):
             self.generate_optimization_problem()
 
     def generate_optimization_problem(self, fixed_initial_state: bool = True):
-        if self._Xf is None:
-            raise NotImplementedError("TrackingMPC without a terminal set (x_N == x_bar, TrackingMPC.py:105-107) is not supported; "
-                                      "call setup_optimization()")
+        """TrackingMPC.py:62-115.  Before `setup_optimization()` / `determine_Xf()` there is no terminal set and the reference
+        constrains x_N == x_bar instead (:105-107); the library eliminates those nx equalities at set-up (tmpc.h:
+        terminal_equality)."""
+        if self._Xc is None:
+            self._Xc, self._Uc = self._X, self._U
         super().generate_optimization_problem(True)
+
+    def _problem_dict(self) -> dict:
+        if self._Xf is not None:
+            return super()._problem_dict()
+        K_anc = self._K if self._K_ancillary is None else self._K_ancillary
+        return dict(nx=self._nx, nu=self._nu, N=self._N, A=self._A, B=self._B, Q=self._Q, R=self._R, P=self._P, T=self._Tout,
+                    K=self._K, K_anc=K_anc, Hx=self._Xc.A, hx=self._Xc.b, Hu=self._Uc.A, hu=self._Uc.b,
+                    fixed_x0=1, extended=0, terminal_equality=1, tol=self._tol, max_iter=self._max_iter)
 
     def solve_optimization_problem(self, x_init, ref, verbose_MPC: bool = False):
         """TrackingMPC.py:117-135 (returns x_mpc, u_mpc, x_bar, u_bar), batched over a leading axis when given one."""

@@ -27,7 +27,7 @@ _up = C.POINTER(C.c_uint8)
 class TmpcProblem(C.Structure):
     """Field-for-field include/tmpc.h: tmpc_problem."""
     _fields_ = ([(n, C.c_int32) for n in _INT_FIELDS] + [("tol", C.c_double)]
-                + [(n, _dp) for n in _PTR_FIELDS] + [("rTP", C.c_int32)])
+                + [(n, _dp) for n in _PTR_FIELDS] + [("rTP", C.c_int32), ("terminal_equality", C.c_int32)])
 
 
 _lib = None
@@ -156,6 +156,7 @@ def pack_problem(d: dict):
     p.rx, p.ru, p.rT = rows.get("Hx", 0), rows.get("Hu", 0), rows.get("HT", 0)
     p.rZ, p.rZW = rows.get("HZ", 0), rows.get("HZW", 0)
     p.rTP = rows.get("HTP", 0)
+    p.terminal_equality = int(d.get("terminal_equality", 0))
     return p, keep
 
 

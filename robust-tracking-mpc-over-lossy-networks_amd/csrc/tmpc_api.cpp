@@ -113,6 +113,15 @@ int upload_common(tmpc_handle *h, Variant &v, const tmpc_problem &p, tmpc::Devic
     if ((rc = upload(h, v, c.gp0.data(), c.gp0.size(), &d.gp0))) return rc;
     if ((rc = upload(h, v, c.Ep.a.data(), c.Ep.a.size(), &d.Ep))) return rc;
     if ((rc = upload(h, v, c.Dv.data(), c.Dv.size(), &d.Dv))) return rc;
+    d.Tzs = d.Txf = nullptr;
+    d.nvf = c.nvf;
+    if (!c.Tz.a.empty()) {
+        std::vector<double> Tzs(c.Tz.a.size());
+        for (int i = 0; i < c.Tz.r; ++i)
+            for (int j = 0; j < c.Tz.c; ++j) Tzs[static_cast<size_t>(i) * c.Tz.c + j] = c.Tz(i, j) * c.Dv[j];
+        if ((rc = upload(h, v, Tzs.data(), Tzs.size(), &d.Tzs))) return rc;
+        if ((rc = upload(h, v, c.Tx.a.data(), c.Tx.a.size(), &d.Txf))) return rc;
+    }
     if ((rc = upload(h, v, c.Mth.a.data(), c.Mth.a.size(), &d.Mth))) return rc;
     if ((rc = upload(h, v, p.A, static_cast<size_t>(nx) * nx, &d.A))) return rc;
     if ((rc = upload(h, v, p.B, static_cast<size_t>(nx) * c.nu, &d.B))) return rc;

@@ -845,16 +845,29 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
         const bool good = st < TMPC_STATUS_INFEASIBLE;
         const double nanv = __longlong_as_double(0x7ff8000000000000ll);
         __syncthreads();
-        if (tid < NVP) tv[tid] = (tid < nv) ? qp.Dv[tid] * zv[tid] : 0.0;     // unscaled z
+        // z_full = [u | theta | x_0 ..]: Dv .* z, or Tzs z + Txf x_k when a further equality was eliminated at set-up
+        // (terminal equality of the tracking MPC; tmpc_condense.hpp)
+        const double *zo = tv;
+        if (qp.Tzs != nullptr) {
+            for (int i = tid; i < qp.nvf; i += BT) {          // nvf <= nv + nx <= 2 BT entries of `parts` (idle here)
+                double v = 0.0;
+                for (int c2 = 0; c2 < nx; ++c2) v += qp.Txf[i * nx + c2] * xin[c2];
+                for (int j = 0; j < nv; ++j) v += qp.Tzs[i * nv + j] * zv[j];
+                parts[i] = v;
+            }
+            zo = parts;
+        } else if (tid < NVP) {
+            tv[tid] = (tid < nv) ? qp.Dv[tid] * zv[tid] : 0.0;     // unscaled z
+        }
         __syncthreads();
-        for (int i = tid; i < N * nu; i += BT) u_nom[b * N * nu + i] = good ? tv[i] : nanv;
+        for (int i = tid; i < N * nu; i += BT) u_nom[b * N * nu + i] = good ? zo[i] : nanv;
         if (tid < nx + nu && xu_ss) {
             double v = 0.0;
-            for (int j = 0; j < qp.nth; ++j) v += qp.Mth[tid * qp.nth + j] * tv[qp.off_theta + j];
+            for (int j = 0; j < qp.nth; ++j) v += qp.Mth[tid * qp.nth + j] * zo[qp.off_theta + j];
             xu_ss[b * (nx + nu) + tid] = good ? v : nanv;
         }
         if (tid < nx) {
-            const double x0 = (qp.off_x0 >= 0) ? tv[qp.off_x0 + tid] : xin[tid];
+            const double x0 = (qp.off_x0 >= 0) ? zo[qp.off_x0 + tid] : xin[tid];
             if (x_nom0) x_nom0[b * nx + tid] = good ? x0 : nanv;
             uv[tid] = x0;
         }
@@ -865,7 +878,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                 double v = 0.0;
                 if (tid < nx) {
                     for (int j = 0; j < nx; ++j) v += qp.A[tid * nx + j] * uv[j];
-                    for (int j = 0; j < nu; ++j) v += qp.B[tid * nu + j] * tv[i * nu + j];
+                    for (int j = 0; j < nu; ++j) v += qp.B[tid * nu + j] * zo[i * nu + j];
                 }
                 __syncthreads();
                 if (tid < nx) { uv[tid] = v; x_nom[b * (N + 1) * nx + (i + 1) * nx + tid] = good ? v : nanv; }

@@ -146,28 +146,80 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     Condensed c;
     c.nx = nx; c.nu = nu; c.N = N; c.nth = nth; c.Mth = Mth;
     c.off_theta = N * nu;
-    int nv = N * nu + nth;
-    if (!fixed) { c.off_x0 = nv; nv += nx; }
-    if (aux) { c.off_aux = nv; nv += nx + nu; }
-    c.nv = nv;
+    int nvf = N * nu + nth;              // the parametrisation z_full = [u | theta | x_0 | aux] the outputs are read from
+    if (!fixed) { c.off_x0 = nvf; nvf += nx; }
+    if (aux) { c.off_aux = nvf; nvf += nx + nu; }
+    const bool term_eq = !received && p.terminal_equality != 0;
+    if (term_eq && p.rT > 0) return "terminal_equality and a terminal set (rT > 0) exclude each other";
 
+    // z_full = Tz z + Tx x_k.  Identity unless an equality is eliminated below; the signals of the horizon are affine in
+    // (z, x_k, ref) either way.
+    Mat Tz = eye(nvf), Tx(nvf, nx);
+    int nv = nvf;
+    std::vector<Aff> x(N + 1), u(N);
+    Aff xbar, ubar;
     auto selector = [&](int dim, int off) {
         Aff s(dim, nv, nx);
-        for (int i = 0; i < dim; ++i) s.L(i, off + i) = 1.0;
+        for (int i = 0; i < dim; ++i) {
+            for (int j = 0; j < nv; ++j) s.L(i, j) = Tz(off + i, j);
+            for (int j = 0; j < nx; ++j) s.Dx(i, j) = Tx(off + i, j);
+        }
         return s;
     };
-    std::vector<Aff> x(N + 1), u(N);
-    for (int i = 0; i < N; ++i) u[i] = selector(nu, i * nu);
-    if (fixed) { x[0] = Aff(nx, nv, nx); x[0].Dx = eye(nx); }
-    else x[0] = selector(nx, c.off_x0);
-    for (int i = 0; i < N; ++i) {
-        x[i + 1] = Aff(nx, nv, nx);
-        x[i + 1].L = add(mul(A, x[i].L), mul(B, u[i].L));
-        x[i + 1].Dx = mul(A, x[i].Dx);
+    auto build_signals = [&]() {
+        for (int i = 0; i < N; ++i) u[i] = selector(nu, i * nu);
+        if (fixed) { x[0] = Aff(nx, nv, nx); x[0].Dx = eye(nx); }
+        else x[0] = selector(nx, c.off_x0);
+        for (int i = 0; i < N; ++i) {
+            x[i + 1] = Aff(nx, nv, nx);
+            x[i + 1].L = add(mul(A, x[i].L), mul(B, u[i].L));
+            x[i + 1].Dx = add(mul(A, x[i].Dx), mul(B, u[i].Dx));
+        }
+        const Aff th = selector(nth, c.off_theta);
+        xbar = Aff(nx, nv, nx);
+        ubar = Aff(nu, nv, nx);
+        Mat Mx(nx, nth), Mu(nu, nth);
+        for (int i = 0; i < nx; ++i) for (int j = 0; j < nth; ++j) Mx(i, j) = Mth(i, j);
+        for (int i = 0; i < nu; ++i) for (int j = 0; j < nth; ++j) Mu(i, j) = Mth(nx + i, j);
+        xbar.L = mul(Mx, th.L); xbar.Dx = mul(Mx, th.Dx);
+        ubar.L = mul(Mu, th.L); ubar.Dx = mul(Mu, th.Dx);
+    };
+    build_signals();
+    if (term_eq) {
+        // TrackingMPC without a terminal set (TrackingMPC.py:105-107): x_N == x_bar, nx more equalities.  They are eliminated like
+        // the others: C z_full + Cx x_k = 0 with C = L(x_N) - L(x_bar);  z_full = -C^+ Cx x_k + null(C) z.
+        const Mat C = add(x[N].L, xbar.L, -1.0), Cx = add(x[N].Dx, xbar.Dx, -1.0);
+        Mat Nc;
+        if (!null_space(C, Nc)) return "terminal equality x_N == x_bar: the horizon is too short to reach a steady state (rank deficient)";
+        Mat CCt = mul(C, tr(C));
+        if (!cholesky(CCt)) return "terminal equality x_N == x_bar: rank deficient";
+        // W = (C C')^-1 Cx by two triangular solves per column, then Tx = -C' W
+        Mat W(nx, nx);
+        for (int k = 0; k < nx; ++k) {
+            std::vector<double> col(nx);
+            for (int i = 0; i < nx; ++i) {
+                double t = Cx(i, k);
+                for (int j = 0; j < i; ++j) t -= CCt(i, j) * col[j];
+                col[i] = t / CCt(i, i);
+            }
+            for (int i = nx - 1; i >= 0; --i) {
+                double t = col[i];
+                for (int j = i + 1; j < nx; ++j) t -= CCt(j, i) * col[j];
+                col[i] = t / CCt(i, i);
+            }
+            for (int i = 0; i < nx; ++i) W(i, k) = col[i];
+        }
+        Tx = mul(tr(C), W);
+        for (double &v : Tx.a) v = -v;
+        Tz = Nc;
+        nv = Nc.c;
+        if (nv < 1) return "terminal equality x_N == x_bar leaves no degree of freedom";
+        build_signals();
+        c.Tz = Tz;
+        c.Tx = Tx;
     }
-    Aff xbar(nx, nv, nx), ubar(nu, nv, nx);
-    for (int i = 0; i < nx; ++i) for (int j = 0; j < nth; ++j) xbar.L(i, c.off_theta + j) = Mth(i, j);
-    for (int i = 0; i < nu; ++i) for (int j = 0; j < nth; ++j) ubar.L(i, c.off_theta + j) = Mth(nx + i, j);
+    c.nv = nv;
+    c.nvf = nvf;
     Aff rsig(nx, nv, nx);
     rsig.Dr = eye(nx);
 
@@ -259,8 +311,10 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     {
         const Aff xT = aux ? selector(nx, c.off_aux) : x[N];
         for (int i = 0; i < nx; ++i) for (int j = 0; j < nv; ++j) PsiT(i, j) = xT.L(i, j);
-        for (int i = 0; i < nth; ++i) PsiT(nx + i, c.off_theta + i) = 1.0;
-        if (aux) for (int i = 0; i < nu; ++i) PsiT(nx + nth + i, c.off_aux + nx + i) = 1.0;
+        if (!term_eq) {          // (with the terminal equality there is no terminal block, and z is not z_full)
+            for (int i = 0; i < nth; ++i) PsiT(nx + i, c.off_theta + i) = 1.0;
+            if (aux) for (int i = 0; i < nu; ++i) PsiT(nx + nth + i, c.off_aux + nx + i) = 1.0;
+        }
         const Mat HT = from_ptr(p.HT, p.rT, 2 * nx + nu);
         for (int r = 0; r < p.rT; ++r) {
             for (int j = 0; j < nx; ++j) HcT(r, j) = HT(r, j);
@@ -355,8 +409,8 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
         if (fblk == 1) {
             for (int a = 0; a < c.kc; ++a) for (int j = 0; j < nv; ++j) c.Psi(a, j) = PsiT(a, j) * c.Dv[j];
         } else {
-            // Hz (x_k - x_0): the rows are -Hz on the x_0 block of z
-            for (int a = 0; a < nx; ++a) c.Psi(a, c.off_x0 + a) = c.Dv[c.off_x0 + a];
+            // Hz (x_k - x_0): the rows are -Hz on the x_0 block of z  (x_0 = rows off_x0.. of Tz z + Tx x_k)
+            for (int a = 0; a < nx; ++a) for (int j = 0; j < nv; ++j) c.Psi(a, j) = Tz(c.off_x0 + a, j) * c.Dv[j];
         }
         double worst = 0;
         for (int r = 0; r < c.ncc; ++r) {

@@ -34,6 +34,8 @@ struct Mat {
 struct Condensed {
     int nx = 0, nu = 0, N = 0;
     int nv = 0;        // decision variables
+    int nvf = 0;       // length of z_full = [u | theta | x_0 | aux] = Tz z + Tx x_k, which the outputs are read from
+    Mat Tz, Tx;        // nvf x nv, nvf x nx; empty = identity / zero (no equality eliminated beyond the standard ones)
     int nc = 0;        // inequality rows the solver iterates on
     int npar = 0;      // rows that depend on x_k only
     int nth = 0;       // dim(theta)

@@ -40,6 +40,9 @@ struct DeviceQP {
     const double *gp0;    // [npar]
     const double *Ep;     // [npar][nx]
     const double *Dv;     // [nv]
+    const double *Tzs;    // [nvf][nv]  z_full = Tzs zs + Txf x_k (Dv folded in); NULL: z_full = Dv .* zs  (tmpc_condense.hpp: Tz, Tx)
+    const double *Txf;    // [nvf][nx]
+    int nvf;              // length of z_full = [u | theta | x_0 | aux]; the outputs are read from it at off_theta / off_x0
     const double *Mth;    // [nx+nu][nth]
     const double *A;      // [nx][nx]
     const double *B;      // [nx][nu]

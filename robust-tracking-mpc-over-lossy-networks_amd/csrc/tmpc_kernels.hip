@@ -1170,19 +1170,32 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         TMPC_REFRESH();
         const bool good = st < TMPC_STATUS_INFEASIBLE;
         const double nanv = __longlong_as_double(0x7ff8000000000000ll);
-        // zu = Dv .* z -> zv (LDS) so that any lane can read any entry
+        // z_full = [u | theta | x_0 ..] in LDS so that any lane can read any entry: Dv .* z, or -- when a further equality was
+        // eliminated at set-up (terminal equality of the tracking MPC) -- Tzs z + Txf x_k
         wave_lds_fence();
-        if (lane < NV) zv[lane] = (lane < qp.nv) ? qp.Dv[lane] * zv[lane] : 0.0;
+        const double *zo = zv;
+        if (qp.Tzs != nullptr) {
+            double *zf = hw;                       // (the region of h is free here: nvf <= NV + nx entries)
+            for (int i = lane; i < qp.nvf; i += WAVE) {
+                double v = 0.0;
+                for (int c = 0; c < nx; ++c) v += qp.Txf[i * nx + c] * xin[c];
+                for (int j = 0; j < qp.nv; ++j) v += qp.Tzs[i * qp.nv + j] * zv[j];
+                zf[i] = v;
+            }
+            zo = zf;
+        } else if (lane < NV) {
+            zv[lane] = (lane < qp.nv) ? qp.Dv[lane] * zv[lane] : 0.0;
+        }
         wave_lds_fence();
-        for (int i = lane; i < N * nu; i += WAVE) u_nom[b * N * nu + i] = good ? zv[i] : nanv;
+        for (int i = lane; i < N * nu; i += WAVE) u_nom[b * N * nu + i] = good ? zo[i] : nanv;
         if (lane < nx + nu) {
             double v = 0.0;
-            for (int j = 0; j < qp.nth; ++j) v += qp.Mth[lane * qp.nth + j] * zv[qp.off_theta + j];
+            for (int j = 0; j < qp.nth; ++j) v += qp.Mth[lane * qp.nth + j] * zo[qp.off_theta + j];
             if (xu_ss) xu_ss[b * (nx + nu) + lane] = good ? v : nanv;
         }
         // x_nom: x_0 then the recursion x_{i+1} = A x_i + B u_i (reference :138)
         if (lane < nx) {
-            const double x0 = (qp.off_x0 >= 0) ? zv[qp.off_x0 + lane] : xin[lane];
+            const double x0 = (qp.off_x0 >= 0) ? zo[qp.off_x0 + lane] : xin[lane];
             if (x_nom0) x_nom0[b * nx + lane] = good ? x0 : nanv;
             tv[lane] = x0;
         }
@@ -1193,7 +1206,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 double v = 0.0;
                 if (lane < nx) {
                     for (int j = 0; j < nx; ++j) v += qp.A[lane * nx + j] * tv[j];
-                    for (int j = 0; j < nu; ++j) v += qp.B[lane * nu + j] * zv[i * nu + j];
+                    for (int j = 0; j < nu; ++j) v += qp.B[lane * nu + j] * zo[i * nu + j];
                 }
                 wave_lds_fence();
                 if (lane < nx) { tv[lane] = v; x_nom[b * (N + 1) * nx + (i + 1) * nx + lane] = good ? v : nanv; }

@@ -1,4 +1,6 @@
 """R-MPC comparator (reference TrackingMPC.py) on the device kernels."""
+import os
+
 import numpy as np
 import pytest
 
@@ -31,10 +33,77 @@ def test_problem_is_the_untightened_fixed_x0_qp(oracle_lib):
     assert sol["status"][0] == 0
     # x = (7.9, 0.9): the next state 8.8 leaves X whatever the bounded input does -> infeasible (U_t = None in the reference)
     assert sol["status"][1] == 2
-    # terminal-set requirement of this implementation
-    bare = TrackingMPC(w["A"], w["B"], w["Q"], w["R"], 10)
-    with pytest.raises(NotImplementedError):
-        bare.generate_optimization_problem()
+
+
+def _bare(name, N):
+    """TrackingMPC before setup_optimization(): no terminal set, x_N == x_bar instead (TrackingMPC.py:105-107)."""
+    w = workloads.double_integrator() if name == "double_integrator" else workloads.cartpole()
+    mpc = TrackingMPC(w["A"], w["B"], w["Q"], w["R"], N)
+    mpc.set_input_constraints(w["U"])
+    mpc.set_state_constraints(w["X"])
+    mpc._Xc, mpc._Uc = mpc._X, mpc._U
+    mpc._fixed_initial_state = True
+    return mpc, w
+
+
+def test_terminal_equality_in_the_oracle(oracle_lib):
+    """The oracle's restatement of TrackingMPC.py:105-107 (x_N == x_bar, eliminated numerically with the other equalities):
+    KKT-certified on the un-condensed QP, and the equality holds in the returned trajectory."""
+    from oracle import qp_sparse
+    mpc, w = _bare("double_integrator", 10)
+    p = mpc._problem_dict()
+    assert p["terminal_equality"] == 1 and "HT" not in p
+    orc = Oracle(p)
+    rng = np.random.default_rng(2)
+    X = rng.uniform(-1, 1, (48, 2)) * [5.0, 0.8]
+    R = np.c_[rng.uniform(-6, 6, 48), np.zeros(48)]
+    sol = orc.solve(X, R)
+    ok = sol["status"] == 0
+    assert ok.sum() > 20
+    np.testing.assert_allclose(sol["x_nom"][ok][:, -1], sol["x_ss"][ok], atol=1e-9)
+    for k in np.flatnonzero(ok)[:24]:
+        qp = qp_sparse.build_sparse_qp(p, X[k], R[k])
+        v = qp_sparse.pack(qp, sol["x_nom"][k], sol["u_nom"][k], sol["x_ss"][k], sol["u_ss"][k])
+        c = qp_sparse.kkt_certificate(qp, v)
+        assert c["r_eq"] < 1e-9 and c["r_ineq"] < 1e-9 and c["r_stat"] < 1e-7 and c["min_lam"] > -1e-9, c
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,N,path", [("double_integrator", 10, "wave"), ("double_integrator", 10, "block"),
+                                         ("cartpole", 20, "auto")])
+def test_terminal_equality_on_the_device(hip_lib, oracle_lib, name, N, path):
+    """TrackingMPC without a terminal set on both kernels: statuses and minimisers of the oracle, x_N == x_bar, and the
+    solver-independent KKT certificate on the un-condensed QP with the equality rows."""
+    from oracle import qp_sparse
+    mpc, w = _bare(name, N)
+    mpc.generate_optimization_problem()
+    mpc.set_kernel_path(path)
+    p = mpc._problem_dict()
+    orc = Oracle(p)
+    rng = np.random.default_rng(4)
+    nx = w["A"].shape[0]
+    if name == "double_integrator":
+        X = rng.uniform(-1, 1, (96, 2)) * [5.0, 0.8]
+        R = np.c_[rng.uniform(-6, 6, 96), np.zeros(96)]
+    else:
+        S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
+        idx = rng.choice(len(S), 96, replace=False)
+        X, R = S[idx, :4] * 0.5, S[idx, 4:] * 0.3
+    ref = orc.solve(X, R)
+    x_mpc, u_mpc, x_bar, u_bar = mpc.solve_optimization_problem(X, R)
+    assert np.array_equal(mpc.last_status, ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() > 20
+    np.testing.assert_allclose(u_mpc[ok], ref["u_nom"][ok], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(x_bar[ok], ref["x_ss"][ok], atol=1e-9, rtol=0)
+    np.testing.assert_allclose(x_mpc[ok][:, -1], x_bar[ok], atol=1e-9, rtol=0)             # x_N == x_bar
+    for k in np.flatnonzero(ok)[:32]:
+        qp = qp_sparse.build_sparse_qp(p, X[k], R[k])
+        v = qp_sparse.pack(qp, x_mpc[k], u_mpc[k], x_bar[k], u_bar[k])
+        c = qp_sparse.kkt_certificate_fast(qp, v)
+        assert c["r_eq"] < 1e-9 and c["r_ineq"] < 1e-9 and c["r_stat"] < 1e-7 and c["min_lam"] > -1e-9, c
+    pkt = mpc.determine_packet(X[np.flatnonzero(ok)[0]].copy(), R[np.flatnonzero(ok)[0]].copy(), 2)
+    assert pkt["U_t"].shape == (w["B"].shape[1], N + 1)
 
 
 @pytest.mark.gpu
