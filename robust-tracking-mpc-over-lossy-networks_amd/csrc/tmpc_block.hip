@@ -35,8 +35,9 @@ namespace {
 
 using namespace wv;
 
-constexpr int BT = 256;          // threads per workgroup
-constexpr int BW = BT / WAVE;    // waves per workgroup
+// threads per workgroup: 256 (4 waves, two workgroups per CU where the LDS allows) up to 64 variables; 512 (8 waves, one
+// workgroup per CU = two waves per SIMD) for the 128-variable shape, whose LDS footprint admits one workgroup only
+constexpr int block_threads(int tiles) { return tiles >= 8 ? 512 : 256; }
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // rows of the per-workgroup workspace, each [ncp] doubles
@@ -47,6 +48,8 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 template <int T>
 struct BShape {
     static constexpr int NVP = 16 * T;
+    static constexpr int BT = block_threads(T);
+    static constexpr int BW = BT / WAVE;                             // waves per workgroup
     static constexpr int LDM = NVP + 1;                              // odd stride: conflict-free column walks
     static constexpr int WCAP = NVP >= 128 ? 128 : NVP + 16;         // working-set rows of the refinement
     static constexpr int LDSS = WCAP + 1;
@@ -55,13 +58,13 @@ struct BShape {
     static constexpr int G = T >= 2 ? T / 2 : 1;                     // tile groups of the MFMA pass
     static constexpr int RSPLIT = BW / G;                            // row parts of the MFMA pass
     static constexpr int NVEC = 10;                                  // nv-vectors
-    static constexpr int SMALL = NVEC * NVP + 2 * BT + 2 * WCAP + cmax(NVP, WCAP) + WCAP /*Widx as ints, padded*/ + 32 + 32;
+    static constexpr int SMALL = NVEC * NVP + 2 * BT + 2 * WCAP + cmax(NVP, WCAP) + WCAP /*Widx as ints, padded*/ + 32 + 48;
     static constexpr int TOTAL = BIG + SMALL;
     // resident workgroups per CU the LDS footprint allows (capped at 4) = waves per SIMD the register budget is set for
     static constexpr int OCC = (160 * 1024 / 8) / TOTAL >= 2 ? 2 : 1;
 };
 
-template <class OpA, class OpB, class OpC>
+template <int BW, class OpA, class OpB, class OpC>
 __device__ __forceinline__ void block_reduce3(double &a, double &b, double &c, double *red, int wave, int lane) {
     a = wave_reduce<OpA>(a);
     b = wave_reduce<OpB>(b);
@@ -69,17 +72,20 @@ __device__ __forceinline__ void block_reduce3(double &a, double &b, double &c, d
     __syncthreads();
     if (lane == 0) { red[wave] = a; red[BW + wave] = b; red[2 * BW + wave] = c; }
     __syncthreads();
-    a = OpA::f(OpA::f(red[0], red[1]), OpA::f(red[2], red[3]));
-    b = OpB::f(OpB::f(red[BW + 0], red[BW + 1]), OpB::f(red[BW + 2], red[BW + 3]));
-    c = OpC::f(OpC::f(red[2 * BW + 0], red[2 * BW + 1]), OpC::f(red[2 * BW + 2], red[2 * BW + 3]));
+    a = red[0]; b = red[BW]; c = red[2 * BW];
+#pragma unroll
+    for (int w = 1; w < BW; ++w) { a = OpA::f(a, red[w]); b = OpB::f(b, red[BW + w]); c = OpC::f(c, red[2 * BW + w]); }
 }
-template <class Op>
+template <int BW, class Op>
 __device__ __forceinline__ double block_reduce1(double a, double *red, int wave, int lane) {
     a = wave_reduce<Op>(a);
     __syncthreads();
     if (lane == 0) red[wave] = a;
     __syncthreads();
-    return Op::f(Op::f(red[0], red[1]), Op::f(red[2], red[3]));
+    a = red[0];
+#pragma unroll
+    for (int w = 1; w < BW; ++w) a = Op::f(a, red[w]);
+    return a;
 }
 
 // G_row(r) . v for the thread's row: column-major copy, v in LDS (broadcast reads).  Eight loads in flight per
@@ -106,7 +112,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
 template <int T>
 __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
                                             double *parts, double *out_a, double *out_b, int tid, const BlockQP &bq) {
-    constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS;
+    constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS, BT = BShape<T>::BT;
     const int j = tid % NVP, part = tid / NVP;
     double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
     int r = bq.nz4 + part;                 // general rows; the initial-state rows [0, nz4) follow below
@@ -256,7 +262,7 @@ template <int T>
 __device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm, const double *__restrict__ dvec, const BlockQP &bq,
                                                   double *M, double *parts, int tid) {
     if (bq.nz4 <= 0) return;
-    constexpr int NVP = BShape<T>::NVP, LDM = BShape<T>::LDM;
+    constexpr int NVP = BShape<T>::NVP, LDM = BShape<T>::LDM, BT = BShape<T>::BT;
     const int P = bq.znx * (bq.znx + 1) / 2;           // <= 136
     const int Q = BT / P;
     const int p = tid % P, q = tid / P;
@@ -318,14 +324,15 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
 // dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a non-positive pivot.
 template <int NB>
 __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid) {
-    const int tx = tid & 15, ty = tid >> 4;
+    const bool own = tid < 256;                   // a 512-thread workgroup factors with its first four waves
+    const int tx = tid & 15, ty = (tid >> 4) & 15;
     double m[NB][NB];
 #pragma unroll
     for (int a = 0; a < NB; ++a)
 #pragma unroll
         for (int b = 0; b <= a; ++b) {
             const int r = ty + 16 * a, c = tx + 16 * b;
-            m[a][b] = (r < n && c <= r) ? Mx[r * ld + c] : 0.0;
+            m[a][b] = (own && r < n && c <= r) ? Mx[r * ld + c] : 0.0;
         }
     bool ok = true;
 #pragma unroll
@@ -334,12 +341,12 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
         for (int jl = 0; jl < 16; ++jl) {
             const int j = 16 * jb + jl;
             if (j >= n) break;
-            if (ty == jl && tx == jl) piv[0] = m[jb][jb];
+            if (own && ty == jl && tx == jl) piv[0] = m[jb][jb];
             __syncthreads();
             const double pjj = piv[0];
             if (!(pjj > 0.0)) { ok = false; break; }
             const double inv = 1.0 / sqrt(pjj);
-            if (tx == jl) {
+            if (own && tx == jl) {
 #pragma unroll
                 for (int a = jb; a < NB; ++a) {
                     const int r = ty + 16 * a;
@@ -427,13 +434,13 @@ __device__ __forceinline__ void wave_llt_solve(const double *L, int ld, int n, c
 #endif
 
 template <int T>
-__global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
+__global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_kernel(
     const DeviceQP qp, const BlockQP bq, double *__restrict__ ws, const int variant_id, const int64_t B,
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
     using SH = BShape<T>;
-    constexpr int NVP = SH::NVP, LDM = SH::LDM, WCAP = SH::WCAP, LDSS = SH::LDSS;
+    constexpr int NVP = SH::NVP, LDM = SH::LDM, WCAP = SH::WCAP, LDSS = SH::LDSS, BT = SH::BT;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double *big = smem;
     double *qv = big + SH::BIG;          // linear term
@@ -452,8 +459,8 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
     double *dinv = dyv + WCAP;           // [max(NVP, WCAP)] reciprocal pivots
     int *Widx = reinterpret_cast<int *>(dinv + cmax(NVP, WCAP));   // [WCAP] (ints in a WCAP-double slot)
     double *xin = reinterpret_cast<double *>(Widx) + WCAP;          // [32] x_k | ref
-    double *red = xin + 32;                                          // [32] reductions / broadcasts
-    int *ibc = reinterpret_cast<int *>(red + 24);                    // a few ints
+    double *red = xin + 32;                                          // [48] reductions (3 x 8 waves) | pivot | ints
+    int *ibc = reinterpret_cast<int *>(red + 40);                    // a few ints
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nv = qp.nv, nc = qp.nc, ncp = bq.ncp;
@@ -523,7 +530,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
             lam_[r] = 0.0;
             if (r < nc) smin_l = fmin(smin_l, sv);
         }
-        block_reduce3<OpMax, OpMax, OpMin>(qn_l, hn_l, smin_l, red, wave, lane);
+        block_reduce3<SH::BW, OpMax, OpMax, OpMin>(qn_l, hn_l, smin_l, red, wave, lane);
         const double qn = qn_l, hn = hn_l, smin = smin_l;
         BSTAMP(0);
 
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         rpn = fmax(rpn, fabs(rp));
                         lmax = fmax(lmax, lv);
                     }
-                    block_reduce3<OpSum, OpMax, OpMax>(gap, rpn, lmax, red, wave, lane);
+                    block_reduce3<SH::BW, OpSum, OpMax, OpMax>(gap, rpn, lmax, red, wave, lane);
                     const double mu = gap / ncd;
                     BSTAMP(1);
                     // ---- P2: cost gradient, G'lam, G'(d.rp)
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         gln = fabs(glv[tid]);
                         rhsv[tid] = -cgj - tv[tid];
                     }
-                    block_reduce3<OpMax, OpSum, OpMax>(rdn, obj, gln, red, wave, lane);
+                    block_reduce3<SH::BW, OpMax, OpSum, OpMax>(rdn, obj, gln, red, wave, lane);
                     BSTAMP(2);
                     if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
                     const double objs = fmax(fabs(obj), 1.0);
@@ -593,7 +600,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                     if (lmax > 1e10) {
                         double hl = 0.0;
                         for (int r = tid; r < nc; r += BT) hl += h_[r] * lam_[r];
-                        hl = block_reduce1<OpSum>(hl, red, wave, lane);
+                        hl = block_reduce1<SH::BW, OpSum>(hl, red, wave, lane);
                         if (hl < 0.0 && gln <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
                     }
                     // ---- P3 + P4: M = Hs + G'DG (MFMA), Cholesky, predictor solve
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         gdg_all<T>(Grm, d_, bq.nz4 / 4, nsteps, big, wave, lane);
                         zblock_accumulate<T>(Grm, d_, bq, big, parts, tid);
                         BSTAMP(4);
-                        spd = block_chol<T>(big, LDM, nv, dinv, red + 16, tid);
+                        spd = block_chol<T>(big, LDM, nv, dinv, red + 32, tid);
                         BSTAMP(5);
                         if (!spd) {
                             // 1e-13 * trace(M), as the oracle does: trace(G'DG) = sum of the weights (unit rows)
@@ -618,7 +625,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             for (int i = 0; i < nv; ++i) trc += qp.Hs[i * NVP + i];
                             double dsum = 0.0;
                             for (int r = tid; r < nc; r += BT) dsum += d_[r];
-                            dsum = block_reduce1<OpSum>(dsum, red, wave, lane);
+                            dsum = block_reduce1<SH::BW, OpSum>(dsum, red, wave, lane);
                             shift = 1e-13 * (trc + dsum);
                         }
                     }
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         c1_[r] = w * rs;
                         rs_[r] = rs;
                     }
-                    block_reduce3<OpMax, OpSum, OpSum>(rho_aff, sb1, sb2, red, wave, lane);
+                    block_reduce3<SH::BW, OpMax, OpSum, OpSum>(rho_aff, sb1, sb2, red, wave, lane);
                     const double aaff = rho_aff > 1.0 ? 1.0 / rho_aff : 1.0;
                     const double mu_aff = (gap + aaff * sb1 + aaff * aaff * sb2) / ncd;
                     double sigma = mu_aff / mu;
@@ -676,7 +683,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                         ds_[r] = dsk;
                         dl_[r] = dlk;
                     }
-                    rho = block_reduce1<OpMax>(rho, red, wave, lane);
+                    rho = block_reduce1<SH::BW, OpMax>(rho, red, wave, lane);
                     const double alpha = rho > tau ? tau / rho : 1.0;
                     // ---- P8: update
                     for (int r = tid; r < ncp; r += BT) {
@@ -739,9 +746,9 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             }
                             __syncthreads();
                             double dmax = (tid < m) ? S[tid * LDSS + tid] : 0.0;
-                            dmax = block_reduce1<OpMax>(dmax, red, wave, lane);
+                            dmax = block_reduce1<SH::BW, OpMax>(dmax, red, wave, lane);
                             if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
-                            if (!block_chol<(WCAP + 15) / 16>(S, LDSS, m, dinv, red + 16, tid)) break;
+                            if (!block_chol<(WCAP + 15) / 16>(S, LDSS, m, dinv, red + 32, tid)) break;
                             for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
                                 if (tid < NVP) {
@@ -784,14 +791,14 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                                 }
                                 if (tid < m) yv[tid] += dyv[tid];
                                 double dum = 0.0;
-                                block_reduce3<OpMax, OpMax, OpMax>(dzl, zl, dum, red, wave, lane);
+                                block_reduce3<SH::BW, OpMax, OpMax, OpMax>(dzl, zl, dum, red, wave, lane);
                                 if (stp >= 1 && dzl <= 1e-14 * zl) break;        // the step no longer moves the iterate
                             }
                         }
                         // ---- verify: primal feasibility on all rows, sign of y on W
                         double ymax = (tid < m) ? fabs(yv[tid]) : 1.0;
                         ymax = fmax(ymax, 1.0);
-                        ymax = block_reduce1<OpMax>(ymax, red, wave, lane);
+                        ymax = block_reduce1<SH::BW, OpMax>(ymax, red, wave, lane);
                         if (tid < m) yall_[Widx[tid]] = yv[tid];
                         __syncthreads();
                         double nviol = 0.0, nneg = 0.0, nloose = 0.0;
@@ -811,7 +818,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                             if (neg) { inW_[r] = 0; yall_[r] = 0.0; }
                             if (viol) { inW_[r] = 1; yall_[r] = 0.0; }
                         }
-                        block_reduce3<OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
+                        block_reduce3<SH::BW, OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
                         // rows of W off their bound with nothing left to correct: not converged, give up (see tmpc_kernels.hip)
                         if (nloose != 0.0 && nviol == 0.0 && nneg == 0.0) break;
                         if (nviol == 0.0 && nneg == 0.0) {
@@ -836,7 +843,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
                 // iteration cap: if the iterate still violates the constraints, call it infeasible
                 double viol = 0.0;
                 for (int r = tid; r < nc; r += BT) viol = fmax(viol, gz_[r] - h_[r]);
-                viol = block_reduce1<OpMax>(viol, red, wave, lane);
+                viol = block_reduce1<SH::BW, OpMax>(viol, red, wave, lane);
                 if (viol > 1e-6 * hn) st = TMPC_STATUS_INFEASIBLE;
             }
         }
@@ -888,7 +895,7 @@ __global__ __launch_bounds__(BT, BShape<T>::OCC) void solve_block_kernel(
         if (tid == 0) { status[b] = st; iters[b] = it_done; }
 #ifdef TMPC_STAMPS
         BSTAMP(11);
-        if (b == 0 && tid == 0 && qp.dbg) { for (int p_ = 0; p_ < 12; ++p_) qp.dbg[p_] = tph[p_]; }
+        if (blockIdx.x == 0 && tid == 0 && qp.dbg && it_done > 0) { for (int p_ = 0; p_ < 12; ++p_) qp.dbg[p_] = tph[p_]; qp.dbg[12] = it_done; }
 #endif
     }
 }
@@ -910,7 +917,7 @@ hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int
     }
     int64_t blocks = B < ws_blocks ? B : ws_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((solve_block_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(BT), lds, stream, qp, bq, ws, variant_id, B,
+    hipLaunchKernelGGL((solve_block_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(BShape<T>::BT), lds, stream, qp, bq, ws, variant_id, B,
                        x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
     return hipGetLastError();
 }
@@ -921,7 +928,7 @@ int block_occupancy_t() {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_block_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               static_cast<int>(lds));
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, solve_block_kernel<T>, BT, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, solve_block_kernel<T>, BShape<T>::BT, lds) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
 
