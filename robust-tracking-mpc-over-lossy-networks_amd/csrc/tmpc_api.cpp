@@ -242,17 +242,38 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const int NVP = 16 * v.tiles, nx = c.nx, ncp = (c.nc + 63) / 64 * 64;
     std::vector<double> Grm(static_cast<size_t>(ncp) * NVP, 0.0), Gcm(Grm.size(), 0.0), GH(Grm.size(), 0.0), g0(ncp, 1.0),
         Es(static_cast<size_t>(ncp) * nx, 0.0);
+    // the Z rows of a free initial state touch x_0 only: the block kernel treats them as a narrow class when there are many
+    const int nz4 = (c.off_x0 >= 0 && c.nz >= 256) ? (c.nz / 4) * 4 : 0;
+    // Staircase of the condensed constraints: the rows of stage k act on u_0 .. u_k only, so the leading rows of G are
+    // zero beyond a few 16-column tiles.  The general rows are ordered by the number of tiles they reach (stable), and the
+    // kernel skips the tiles / columns a row does not touch (exact: the skipped entries are zero).
+    std::vector<int> ext(c.nc, 1), order(c.nc);
     for (int r = 0; r < c.nc; ++r) {
+        int last = 0;
+        for (int j = 0; j < c.nv; ++j)
+            if (c.Gs(r, j) != 0.0) last = j;
+        ext[r] = last / 16 + 1;
+        order[r] = r;
+    }
+    std::stable_sort(order.begin() + nz4, order.end(), [&](int a, int b) { return ext[a] < ext[b]; });
+    std::vector<int32_t> ncols(ncp, c.nv);
+    for (int t = 0; t <= 8; ++t) v.bq.row_start[t] = c.nc;
+    for (int rr = c.nc - 1; rr >= nz4; --rr)
+        for (int t = 0; t < ext[order[rr]] && t <= 8; ++t) v.bq.row_start[t] = rr;
+    v.bq.row_start[0] = nz4;
+    for (int rr = 0; rr < c.nc; ++rr) {
+        const int r = order[rr];
+        ncols[rr] = rr < nz4 ? c.nv : std::min(c.nv, 16 * ext[r]);
         for (int j = 0; j < c.nv; ++j) {
             const double g = c.Gs(r, j);
-            Grm[static_cast<size_t>(r) * NVP + j] = g;
-            Gcm[static_cast<size_t>(j) * ncp + r] = g;
+            Grm[static_cast<size_t>(rr) * NVP + j] = g;
+            Gcm[static_cast<size_t>(j) * ncp + rr] = g;
             double t = 0.0;
             for (int k = 0; k < c.nv; ++k) t += c.Gs(r, k) * c.Hinv(k, j);
-            GH[static_cast<size_t>(r) * NVP + j] = t;
+            GH[static_cast<size_t>(rr) * NVP + j] = t;
         }
-        g0[r] = c.g0s[r];
-        for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(r) * nx + j] = c.Es(r, j);
+        g0[rr] = c.g0s[r];
+        for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(rr) * nx + j] = c.Es(r, j);
     }
     int rc;
     if ((rc = upload_common(h, v, p, v.db, NVP))) return rc;
@@ -260,8 +281,7 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = nullptr;
     v.db.vmask = nullptr; v.db.row_of = nullptr;
     v.bq.ncp = ncp;
-    // the Z rows of a free initial state touch x_0 only: the block kernel treats them as a narrow class when there are many
-    v.bq.nz4 = (c.off_x0 >= 0 && c.nz >= 256) ? (c.nz / 4) * 4 : 0;
+    v.bq.nz4 = nz4;
     v.bq.zx0 = c.off_x0 >= 0 ? c.off_x0 : 0;
     v.bq.znx = nx;
     if ((rc = upload(h, v, Grm.data(), Grm.size(), &v.bq.Grm))) return rc;
@@ -269,6 +289,7 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload(h, v, GH.data(), GH.size(), &v.bq.GHrm))) return rc;
     if ((rc = upload(h, v, g0.data(), g0.size(), &v.bq.g0))) return rc;
     if ((rc = upload(h, v, Es.data(), Es.size(), &v.bq.Es))) return rc;
+    if ((rc = upload(h, v, ncols.data(), ncols.size(), &v.bq.ncols))) return rc;
 #ifdef TMPC_STAMPS
     {
         void *dbgp = nullptr;

@@ -25,6 +25,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <type_traits>
 
 #include "tmpc_device.hpp"
 #include "tmpc_wave.hpp"
@@ -54,11 +55,11 @@ struct BShape {
     static constexpr int WCAP = NVP >= 128 ? 128 : NVP + 16;         // working-set rows of the refinement
     static constexpr int LDSS = WCAP + 1;
     static constexpr int BIG = cmax(NVP * LDM, WCAP * LDSS);         // M / its factor, later S / its factor
-    static constexpr int PARTS = BT / NVP;                           // row parts of a G'v pass
+    static constexpr int PARTS = 2 * BT / NVP;                       // row parts of a G'v pass (a thread owns two columns)
     static constexpr int G = T >= 2 ? T / 2 : 1;                     // tile groups of the MFMA pass
     static constexpr int RSPLIT = BW / G;                            // row parts of the MFMA pass
     static constexpr int NVEC = 10;                                  // nv-vectors
-    static constexpr int SMALL = NVEC * NVP + 2 * BT + 2 * WCAP + cmax(NVP, WCAP) + WCAP /*Widx as ints, padded*/ + 32 + 48;
+    static constexpr int SMALL = NVEC * NVP + 4 * BT + 2 * WCAP + cmax(NVP, WCAP) + WCAP /*Widx as ints, padded*/ + 32 + 48;
     static constexpr int TOTAL = BIG + SMALL;
     // resident workgroups per CU the LDS footprint allows (capped at 4) = waves per SIMD the register budget is set for
     static constexpr int OCC = (160 * 1024 / 8) / TOTAL >= 2 ? 2 : 1;
@@ -96,6 +97,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
         for (int a = 0; a < bq.znx; ++a) t0 = fma(Gcm[static_cast<size_t>(bq.zx0 + a) * ncp + r], v[bq.zx0 + a], t0);
         return t0;
     }
+    nv = bq.ncols[r];                      // the row is zero beyond (staircase, BlockQP::ncols)
     int j = 0;
     for (; j + 8 <= nv; j += 8) {
         double g[8];
@@ -112,36 +114,46 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
 template <int T>
 __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
                                             double *parts, double *out_a, double *out_b, int tid, const BlockQP &bq) {
-    constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS, BT = BShape<T>::BT;
-    const int j = tid % NVP, part = tid / NVP;
-    double a0 = 0.0, b0 = 0.0, a1 = 0.0, b1 = 0.0;
+    constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS, BT = BShape<T>::BT, NV2 = NVP / 2;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    // thread = (column pair, row part): 16-byte loads, a wave covers whole rows of G; the operands come from L2 or beyond
+    // and the pass is bound by the bytes in flight, so eight rows are outstanding per thread
+    const int j2 = tid % NV2, part = tid / NV2;
+    v2d a0 = {0.0, 0.0}, b0 = {0.0, 0.0}, a1 = {0.0, 0.0}, b1 = {0.0, 0.0};
+    const v2d *__restrict__ G2 = reinterpret_cast<const v2d *>(Grm) + j2;
+    const int rs = bq.row_start[(2 * j2) >> 4];   // rows below do not reach this column tile (staircase): not loaded
+    const v2d zero2 = {0.0, 0.0};
     int r = bq.nz4 + part;                 // general rows; the initial-state rows [0, nz4) follow below
-    for (; r + 7 * PARTS < nc; r += 8 * PARTS) {           // eight rows in flight (L2 latency, see row_dot)
-        double g[8], xa[8], xb[8];
+    for (; r + 7 * PARTS < nc; r += 8 * PARTS) {
+        v2d g[8];
+        double xa[8], xb[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            g[k] = Grm[static_cast<size_t>(r + k * PARTS) * NVP + j];
+            g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
             xa[k] = va[r + k * PARTS];
             xb[k] = vb[r + k * PARTS];
         }
 #pragma unroll
         for (int k = 0; k < 8; k += 2) {
-            a0 = fma(g[k], xa[k], a0); b0 = fma(g[k], xb[k], b0);
-            a1 = fma(g[k + 1], xa[k + 1], a1); b1 = fma(g[k + 1], xb[k + 1], b1);
+            a0 += g[k] * xa[k]; b0 += g[k] * xb[k];
+            a1 += g[k + 1] * xa[k + 1]; b1 += g[k + 1] * xb[k + 1];
         }
     }
     for (; r < nc; r += PARTS) {
-        const double g0 = Grm[static_cast<size_t>(r) * NVP + j];
-        a0 = fma(g0, va[r], a0); b0 = fma(g0, vb[r], b0);
+        const v2d g0 = (r >= rs) ? G2[static_cast<size_t>(r) * NV2] : zero2;
+        a0 += g0 * va[r]; b0 += g0 * vb[r];
     }
     __syncthreads();                       // previous readers of `parts` are done
-    parts[part * NVP + j] = a0 + a1;
-    parts[BT + part * NVP + j] = b0 + b1;
+    a0 += a1; b0 += b1;
+    parts[part * NVP + 2 * j2] = a0.x;
+    parts[part * NVP + 2 * j2 + 1] = a0.y;
+    parts[2 * BT + part * NVP + 2 * j2] = b0.x;
+    parts[2 * BT + part * NVP + 2 * j2 + 1] = b0.y;
     __syncthreads();
     if (tid < NVP) {
         double sa = 0.0, sb = 0.0;
 #pragma unroll
-        for (int p = 0; p < PARTS; ++p) { sa += parts[p * NVP + tid]; sb += parts[BT + p * NVP + tid]; }
+        for (int p = 0; p < PARTS; ++p) { sa += parts[p * NVP + tid]; sb += parts[2 * BT + p * NVP + tid]; }
         out_a[tid] = sa;
         out_b[tid] = sb;
     }
@@ -182,15 +194,16 @@ __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int 
     }
 }
 
-// Tiles of the lower triangle of G'DG owned by tile group GI (tile rows RA = GI and RB = T-1-GI),
-// accumulated over the k-steps (4 rows each) rpart, rpart + RSPLIT, ... and added into M (LDS).
-template <int T, int GI>
-__device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int ks0, int nsteps, int rpart,
-                                          double *M, int lane) {
+// Tiles of the lower triangle of G'DG in the tile rows RA < RB (RA = -1: RB only), accumulated over the k-steps (4 rows
+// each) rpart, rpart + RSPLIT, ... and added into M (LDS).  The rows are ordered by the tiles they reach (staircase of the
+// condensed constraints, BlockQP::row_start): tile row t takes k-steps from ks_t on, so the pass runs [ksA, ksB) for
+// the tiles of row RA alone and [ksB, nsteps) for both rows.
+template <int T, int RA, int RB>
+__device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int ksA, int ksB, int nsteps,
+                                          int rpart, double *M, int lane) {
     using SH = BShape<T>;
     constexpr int NVP = SH::NVP, LDM = SH::LDM, RS = SH::RSPLIT;
-    constexpr int RA = T == 1 ? 0 : GI, RB = T == 1 ? 0 : T - 1 - GI;
-    constexpr int NA = T == 1 ? 0 : RA + 1, NB = RB + 1;
+    constexpr int NA = RA + 1, NB = RB + 1;
     constexpr int NAA = NA > 0 ? NA : 1;
     v4d accA[NAA], accB[NB];
 #pragma unroll
@@ -201,41 +214,50 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
     // U k-steps per group, the next group's operands in flight while the current group's MFMAs run:
     // the loads come from L2 (~1-2 k cycles away), one k-step of look-ahead would leave the matrix core idle
     constexpr int U = T >= 4 ? 2 : 4;
-    double cur[U][NB], nxt[U][NB];
-    double dcur[U], dnxt[U];
-    auto load_group = [&](int ks0, double (&g)[U][NB], double (&dv)[U]) {
+    auto pass = [&](auto with_b, int ks_begin, int ks_end) {
+        constexpr bool WB = decltype(with_b)::value;
+        constexpr int NL = WB ? NB : NAA;                 // tiles of a row of G this pass reads
+        double cur[U][NL], nxt[U][NL];
+        double dcur[U], dnxt[U];
+        auto load_group = [&](int ksg, double (&g)[U][NL], double (&dv)[U]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ks = ks0 + u * RS;
-            const bool in = ks < nsteps;
-            const size_t row = static_cast<size_t>(4 * (in ? ks : 0) + kq);
+            for (int u = 0; u < U; ++u) {
+                const int ks = ksg + u * RS;
+                const bool in = ks < ks_end;
+                const size_t row = static_cast<size_t>(4 * (in ? ks : ks_begin) + kq);
 #pragma unroll
-            for (int t = 0; t < NB; ++t) g[u][t] = Grm[row * NVP + 16 * t + c];
-            dv[u] = in ? dvec[row] : 0.0;
-        }
-    };
-    int ks = ks0 + rpart;                       // k-steps below ks0 belong to the initial-state rows (handled apart)
-    load_group(ks, cur, dcur);                  // unconditional (indices are clamped inside): a branch around the
-    for (; ks < nsteps; ks += RS * U) {         // prefetch makes the compiler wait for ALL loads before the MFMAs
-        load_group(ks + RS * U, nxt, dnxt);
+                for (int t = 0; t < NL; ++t) g[u][t] = Grm[row * NVP + 16 * t + c];
+                dv[u] = in ? dvec[row] : 0.0;
+            }
+        };
+        int ks = ks_begin + rpart;
+        if (ks_begin >= ks_end) return;
+        load_group(ks, cur, dcur);                  // unconditional (indices are clamped inside): a branch around the
+        for (; ks < ks_end; ks += RS * U) {         // prefetch makes the compiler wait for ALL loads before the MFMAs
+            load_group(ks + RS * U, nxt, dnxt);
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const double aB = dcur[u] * cur[u][RB];
+            for (int u = 0; u < U; ++u) {
+                if constexpr (WB) {
+                    const double aB = dcur[u] * cur[u][RB];
 #pragma unroll
-            for (int t = 0; t < NB; ++t) accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, cur[u][t], accB[t], 0, 0, 0);
-            if constexpr (NA > 0) {
-                const double aA = dcur[u] * cur[u][RA];
+                    for (int t = 0; t < NB; ++t) accB[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB, cur[u][t], accB[t], 0, 0, 0);
+                }
+                if constexpr (NA > 0) {
+                    const double aA = dcur[u] * cur[u][RA];
 #pragma unroll
-                for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, cur[u][t], accA[t], 0, 0, 0);
+                    for (int t = 0; t < NA; ++t) accA[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA, cur[u][t], accA[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int t = 0; t < NL; ++t) cur[u][t] = nxt[u][t];
+                dcur[u] = dnxt[u];
             }
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-#pragma unroll
-            for (int t = 0; t < NB; ++t) cur[u][t] = nxt[u][t];
-            dcur[u] = dnxt[u];
-        }
-    }
+    };
+    if constexpr (NA > 0) pass(std::false_type{}, ksA, ksB);
+    pass(std::true_type{}, ksB, nsteps);
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
     for (int p = 0; p < RS; ++p) {
@@ -299,131 +321,185 @@ __device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm
 }
 
 template <int T>
-__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, int ks0, int nsteps, double *M,
-                                        int wave, int lane) {
+__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, const BlockQP &bq, int nsteps,
+                                        double *M, int wave, int lane) {
     constexpr int G = BShape<T>::G;
     const int g = wave % G, rpart = wave / G;
+    const int ks0 = bq.nz4 / 4;                    // k-steps below belong to the initial-state rows (handled apart)
+    auto first = [&](int t) { const int k = bq.row_start[t] / 4; return k > ks0 ? k : ks0; };
     if constexpr (G == 1) {
-        gdg_group<T, 0>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        if constexpr (T == 1) gdg_group<T, -1, 0>(Grm, dvec, ks0, ks0, nsteps, rpart, M, lane);
+        else gdg_group<T, 0, 1>(Grm, dvec, first(0), first(1), nsteps, rpart, M, lane);
     } else if constexpr (G == 2) {
-        if (g == 0) gdg_group<T, 0>(Grm, dvec, ks0, nsteps, rpart, M, lane);
-        else gdg_group<T, 1>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        if (g == 0) gdg_group<T, 0, 3>(Grm, dvec, first(0), first(3), nsteps, rpart, M, lane);
+        else gdg_group<T, 1, 2>(Grm, dvec, first(1), first(2), nsteps, rpart, M, lane);
     } else {
-        if (g == 0) gdg_group<T, 0>(Grm, dvec, ks0, nsteps, rpart, M, lane);
-        else if (g == 1) gdg_group<T, 1>(Grm, dvec, ks0, nsteps, rpart, M, lane);
-        else if (g == 2) gdg_group<T, 2>(Grm, dvec, ks0, nsteps, rpart, M, lane);
-        else gdg_group<T, 3>(Grm, dvec, ks0, nsteps, rpart, M, lane);
+        if (g == 0) gdg_group<T, 0, 7>(Grm, dvec, first(0), first(7), nsteps, rpart, M, lane);
+        else if (g == 1) gdg_group<T, 1, 6>(Grm, dvec, first(1), first(6), nsteps, rpart, M, lane);
+        else if (g == 2) gdg_group<T, 2, 5>(Grm, dvec, first(2), first(5), nsteps, rpart, M, lane);
+        else gdg_group<T, 3, 4>(Grm, dvec, first(3), first(4), nsteps, rpart, M, lane);
     }
 }
 
-// Right-looking Cholesky of the n x n lower triangle at Mx (LDS, row stride ld) by the whole workgroup, with the
-// matrix held in REGISTERS: thread (tx, ty) = (tid & 15, tid >> 4) owns the elements (ty + 16 a, tx + 16 b), a >= b
-// (NB (NB+1) / 2 values for n <= 16 NB).  Per column: the owner publishes the pivot, the owners of the column scale it
-// and write it to its final place in LDS, then every thread updates its own elements with two short LDS reads per
-// element row/column -- no read-modify-write chains through LDS.  On return the strictly lower triangle of Mx holds L,
-// dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a non-positive pivot.
-template <int NB>
+// Blocked right-looking Cholesky of the n x n lower triangle at Mx (LDS, odd row stride ld) by the whole workgroup, 16
+// columns per step:
+//   1. wave 0 factors the 16 x 16 diagonal block in registers (lane i holds row i; the pivot row reaches the other
+//      lanes by v_readlane, no LDS round trips in the 16-column chain);
+//   2. one thread per row below solves its row of the panel against the block (L21 = A21 L11^-T);
+//   3. the trailing lower-triangular tiles take A22 -= L21 L21' on the matrix cores (v_mfma_f64_16x16x4_f64, four
+//      k-steps per tile), tiles dealt round-robin to the waves.
+// On return the strictly lower triangle of Mx holds L, dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a
+// non-positive pivot.  Rows and columns >= n are never read as data (masked to zero / identity).
+template <int BWn>
 __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid) {
-    const bool own = tid < 256;                   // a 512-thread workgroup factors with its first four waves
-    const int tx = tid & 15, ty = (tid >> 4) & 15;
-    double m[NB][NB];
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
+    const int nblk = (n + 15) >> 4;
+    const int li = lane & 15, kq = lane >> 4;
+    if (tid == 0) piv[0] = 1.0;
+    for (int kb = 0; kb < nblk; ++kb) {
+        const int c0 = 16 * kb;
+        const int nl = n - c0 < 16 ? n - c0 : 16;
+        __syncthreads();
+        if (wave == 0) {
+            double a[16];
 #pragma unroll
-    for (int a = 0; a < NB; ++a)
+            for (int k = 0; k < 16; ++k) a[k] = (li < nl && k <= li) ? Mx[(c0 + li) * ld + c0 + k] : (k == li ? 1.0 : 0.0);
+            bool good = true;
 #pragma unroll
-        for (int b = 0; b <= a; ++b) {
-            const int r = ty + 16 * a, c = tx + 16 * b;
-            m[a][b] = (own && r < n && c <= r) ? Mx[r * ld + c] : 0.0;
-        }
-    bool ok = true;
+            for (int j = 0; j < 16; ++j) {
+                double pj = readlane_d(a[j], j);
+                if (!(pj > 0.0)) { good = false; pj = 1.0; }
+                double inv = __builtin_amdgcn_rsq(pj);        // 1 / sqrt(p_j): v_rsq_f64 + three Newton steps
 #pragma unroll
-    for (int jb = 0; jb < NB; ++jb) {
-        if (16 * jb >= n || !ok) break;
-        for (int jl = 0; jl < 16; ++jl) {
-            const int j = 16 * jb + jl;
-            if (j >= n) break;
-            if (own && ty == jl && tx == jl) piv[0] = m[jb][jb];
-            __syncthreads();
-            const double pjj = piv[0];
-            if (!(pjj > 0.0)) { ok = false; break; }
-            const double inv = 1.0 / sqrt(pjj);
-            if (own && tx == jl) {
+                for (int nr = 0; nr < 3; ++nr) inv = fma(0.5 * inv, fma(-pj * inv, inv, 1.0), inv);
+                a[j] *= inv;
+                if (lane == 0 && j < nl) dinv[c0 + j] = inv;
 #pragma unroll
-                for (int a = jb; a < NB; ++a) {
-                    const int r = ty + 16 * a;
-                    if (r > j && r < n) { m[a][jb] *= inv; Mx[r * ld + j] = m[a][jb]; }
+                for (int k = j + 1; k < 16; ++k) {
+                    const double lkj = readlane_d(a[j], k);
+                    a[k] = fma(-a[j], lkj, a[k]);
                 }
             }
-            if (tid == 0) dinv[j] = inv;
-            __syncthreads();
-            double lr[NB], lc[NB];
+            if (lane < nl) {
 #pragma unroll
-            for (int a = jb; a < NB; ++a) {
-                const int r = ty + 16 * a, c = tx + 16 * a;
-                lr[a] = (r > j && r < n) ? Mx[r * ld + j] : 0.0;
-                lc[a] = (c > j && c < n) ? Mx[c * ld + j] : 0.0;
+                for (int k = 0; k < 15; ++k)
+                    if (k < lane) Mx[(c0 + lane) * ld + c0 + k] = a[k];
+            }
+            if (!good && lane == 0) piv[0] = 0.0;
+        }
+        __syncthreads();
+        if (piv[0] == 0.0) break;
+        if (kb + 1 == nblk) break;
+        // panel: row r of A21 against L11 (forward substitution along the row)
+        for (int r = c0 + 16 + tid; r < n; r += BWn * WAVE) {
+            double x[16];
+            double *row = Mx + r * ld + c0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) x[k] = row[k];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const double *lj = Mx + (c0 + j) * ld + c0;
+                double v = x[j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) v = fma(-x[k], lj[k], v);
+                x[j] = v * dinv[c0 + j];
             }
 #pragma unroll
-            for (int a = jb; a < NB; ++a)
+            for (int k = 0; k < 16; ++k) row[k] = x[k];
+        }
+        __syncthreads();
+        // trailing update of the tiles (ta, tb), tb <= ta, below / right of the panel
+        const int mt = nblk - kb - 1, ntile = mt * (mt + 1) / 2, base = c0 + 16;
+        for (int t = wave; t < ntile; t += BWn) {
+            int ta = 0, rem = t;
+            while (rem > ta) { rem -= ta + 1; ++ta; }
+            const int tb = rem;
+            const int ri = base + 16 * ta + li, rj = base + 16 * tb + li;
+            v4d acc;
+            double *ct = Mx + (base + 16 * ta + kq) * ld + base + 16 * tb + li;
 #pragma unroll
-                for (int b = jb; b <= a; ++b) m[a][b] = fma(-lr[a], lc[b], m[a][b]);
+            for (int reg = 0; reg < 4; ++reg) acc[reg] = ct[4 * reg * ld];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const double av = ri < n ? -Mx[ri * ld + c0 + 4 * s4 + kq] : 0.0;
+                const double bv = rj < n ? Mx[rj * ld + c0 + 4 * s4 + kq] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) ct[4 * reg * ld] = acc[reg];
         }
     }
+    __syncthreads();
+    const bool ok = piv[0] != 0.0;
     __syncthreads();
     return ok;
 }
 
-// L L' x = b in one wave (n <= 128): lane l holds entries l and l + 64.  b and x may alias.  The entries of L and
-// the reciprocal pivots of eight columns are fetched ahead of the eight dependent steps that use them, so that the
-// chain per step is readlane - multiply - fma and not an LDS round trip.
+// L L' x = b in one wave, blocked by 16 columns.  b and x may alias.  Lane (i, q) = (lane & 15, lane >> 4):
+// per block the four q-groups share the dot products with the part of the solution already known (left-looking, LDS
+// reads only), then the 16 x 16 diagonal block is solved with the block's rows / columns of L in registers and the
+// pivot value travelling by v_readlane -- the dependent chain per column is multiply - readlane - fma.
 __device__ __forceinline__ void wave_llt_solve(const double *L, int ld, int n, const double *dinv, const double *b, double *x, int lane,
                                                int nfill = 0) {
-    const int i0 = lane, i1 = lane + WAVE;
-    const int r0 = i0 < n ? i0 : 0, r1 = i1 < n ? i1 : 0;
-    double b0 = i0 < n ? b[i0] : 0.0, b1 = i1 < n ? b[i1] : 0.0;
-    for (int j0 = 0; j0 < n; j0 += 8) {
-        double l0[8], l1[8], di[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = (j0 + k < n) ? j0 + k : n - 1;
-            di[k] = dinv[j];
-            l0[k] = L[r0 * ld + j];
-            l1[k] = L[r1 * ld + j];
+    const int i = lane & 15, q = lane >> 4;
+    const int nblk = (n + 15) >> 4;
+    for (int kb = 0; kb < nblk; ++kb) {                      // L y = b
+        const int c0 = 16 * kb, r = c0 + i;
+        const bool in = r < n;
+        const double *Lr = L + (in ? r : 0) * ld;
+        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        for (int c = q; c < c0; c += 16) {                   // c0 is a multiple of 16: four independent LDS read pairs per trip
+            acc = fma(Lr[c], x[c], acc);
+            acc1 = fma(Lr[c + 4], x[c + 4], acc1);
+            acc2 = fma(Lr[c + 8], x[c + 8], acc2);
+            acc3 = fma(Lr[c + 12], x[c + 12], acc3);
         }
+        acc = (acc + acc1) + (acc2 + acc3);
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        double l[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = j0 + k;
-            if (j < n) {
-                const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
-                const double yj = bj * di[k];
-                if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = yj; else b1 = yj; }
-                if (i0 > j && i0 < n) b0 = fma(-l0[k], yj, b0);
-                if (i1 > j && i1 < n) b1 = fma(-l1[k], yj, b1);
-            }
+        for (int k = 0; k < 16; ++k) l[k] = (in && k < i) ? Lr[c0 + k] : 0.0;
+        const double di = in ? dinv[r] : 0.0;
+        double t = in ? b[r] - acc : 0.0, res = 0.0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double yj = readlane_d(t * di, j);
+            t = fma(-l[j], yj, t);
+            res = (i == j) ? yj : res;
         }
+        if (q == 0 && in) x[r] = res;
     }
-    for (int j0 = ((n - 1) / 8) * 8; j0 >= 0; j0 -= 8) {
-        double l0[8], l1[8], di[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int j = (j0 + k < n) ? j0 + k : n - 1;
-            di[k] = dinv[j];
-            l0[k] = L[j * ld + r0];
-            l1[k] = L[j * ld + r1];
+    for (int kb = nblk - 1; kb >= 0; --kb) {                 // L' x = y
+        const int c0 = 16 * kb, r = c0 + i;
+        const bool in = r < n;
+        const double *Lc = L + (in ? r : 0);
+        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+        int rr = c0 + 16 + q;
+        for (; rr + 12 < n; rr += 16) {
+            acc = fma(Lc[rr * ld], x[rr], acc);
+            acc1 = fma(Lc[(rr + 4) * ld], x[rr + 4], acc1);
+            acc2 = fma(Lc[(rr + 8) * ld], x[rr + 8], acc2);
+            acc3 = fma(Lc[(rr + 12) * ld], x[rr + 12], acc3);
         }
+        for (; rr < n; rr += 4) acc = fma(Lc[rr * ld], x[rr], acc);
+        acc = (acc + acc1) + (acc2 + acc3);
+        acc += __shfl_xor(acc, 16);
+        acc += __shfl_xor(acc, 32);
+        double l[16];
 #pragma unroll
-        for (int k = 7; k >= 0; --k) {
-            const int j = j0 + k;
-            if (j < n) {
-                const double bj = j < WAVE ? readlane_d(b0, j) : readlane_d(b1, j - WAVE);
-                const double xj = bj * di[k];
-                if (lane == (j & (WAVE - 1))) { if (j < WAVE) b0 = xj; else b1 = xj; }
-                if (i0 < j) b0 = fma(-l0[k], xj, b0);
-                if (i1 < j) b1 = fma(-l1[k], xj, b1);
-            }
+        for (int k = 0; k < 16; ++k) l[k] = (in && k > i && c0 + k < n) ? Lc[(c0 + k) * ld] : 0.0;
+        const double di = in ? dinv[r] : 0.0;
+        double t = in ? x[r] - acc : 0.0, res = 0.0;
+#pragma unroll
+        for (int j = 15; j >= 0; --j) {
+            const double xj = readlane_d(t * di, j);
+            t = fma(-l[j], xj, t);
+            res = (i == j) ? xj : res;
         }
+        if (q == 0 && in) x[r] = res;
     }
-    if (i0 < n) x[i0] = b0; else if (i0 < nfill) x[i0] = 0.0;      // entries n..nfill-1 (padding) are cleared
-    if (i1 < n) x[i1] = b1; else if (i1 < nfill) x[i1] = 0.0;
+    for (int k = n + lane; k < nfill; k += WAVE) x[k] = 0.0;  // entries n..nfill-1 (padding) are cleared
 }
 
 // Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of workgroup 0, written to qp.dbg
@@ -453,8 +529,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
     double *tv = zpv + NVP;              // scratch
     double *uv = tv + NVP;               // scratch
     double *glv = uv + NVP;              // G' lambda
-    double *parts = glv + NVP;           // [2][BT] partial sums of a G'v pass
-    double *yv = parts + 2 * BT;         // [WCAP]
+    double *parts = glv + NVP;           // [2][2 BT] partial sums of a G'v pass
+    double *yv = parts + 4 * BT;         // [WCAP]
     double *dyv = yv + WCAP;             // [WCAP]
     double *dinv = dyv + WCAP;           // [max(NVP, WCAP)] reciprocal pivots
     int *Widx = reinterpret_cast<int *>(dinv + cmax(NVP, WCAP));   // [WCAP] (ints in a WCAP-double slot)
@@ -614,10 +690,10 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         }
                         __syncthreads();
                         BSTAMP(3);
-                        gdg_all<T>(Grm, d_, bq.nz4 / 4, nsteps, big, wave, lane);
+                        gdg_all<T>(Grm, d_, bq, nsteps, big, wave, lane);
                         zblock_accumulate<T>(Grm, d_, bq, big, parts, tid);
                         BSTAMP(4);
-                        spd = block_chol<T>(big, LDM, nv, dinv, red + 32, tid);
+                        spd = block_chol<SH::BW>(big, LDM, nv, dinv, red + 32, tid);
                         BSTAMP(5);
                         if (!spd) {
                             // 1e-13 * trace(M), as the oracle does: trace(G'DG) = sum of the weights (unit rows)
@@ -748,7 +824,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             double dmax = (tid < m) ? S[tid * LDSS + tid] : 0.0;
                             dmax = block_reduce1<SH::BW, OpMax>(dmax, red, wave, lane);
                             if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
-                            if (!block_chol<(WCAP + 15) / 16>(S, LDSS, m, dinv, red + 32, tid)) break;
+                            if (!block_chol<SH::BW>(S, LDSS, m, dinv, red + 32, tid)) break;
                             for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
                                 if (tid < NVP) {

@@ -58,6 +58,8 @@ struct BlockQP {
     const double *GHrm;   // [ncp][NVP]  G * Hs^-1, row-major (refinement: S = G_W Hs^-1 G_W')
     const double *g0;     // [ncp]       right-hand side offsets (padding rows: 1)
     const double *Es;     // [ncp][nx]   right-hand side dependence on x_k
+    const int32_t *ncols; // [ncp]       columns a row reaches (its zeros beyond are skipped); rows >= nz4 are ordered by it
+    int row_start[9];     // row_start[t]: first row that reaches the 16-column tile t (row_start[0] = nz4; nc if none)
 };
 
 struct KernelShape {
