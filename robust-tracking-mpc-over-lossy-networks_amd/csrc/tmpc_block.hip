@@ -435,71 +435,132 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
     return ok;
 }
 
-// L L' x = b in one wave, blocked by 16 columns.  b and x may alias.  Lane (i, q) = (lane & 15, lane >> 4):
-// per block the four q-groups share the dot products with the part of the solution already known (left-looking, LDS
-// reads only), then the 16 x 16 diagonal block is solved with the block's rows / columns of L in registers and the
-// pivot value travelling by v_readlane -- the dependent chain per column is multiply - readlane - fma.
-__device__ __forceinline__ void wave_llt_solve(const double *L, int ld, int n, const double *dinv, const double *b, double *x, int lane,
-                                               int nfill = 0) {
-    const int i = lane & 15, q = lane >> 4;
+// W = L^-1 for the factor left by block_chol, by the whole workgroup; W' goes to the strictly UPPER triangle of Mx
+// (W[i][k], k < i, at Mx[k * ld + i]; its diagonal is dinv), the strictly lower triangle is used up.  With W the two
+// triangular solves of an iteration -- 2 x 2 n dependent steps in one wave -- become two matrix-vector products by all
+// threads (block_inv_solve).  Three steps on 16 x 16 tiles:
+//   I.   the diagonal blocks: lane c of a wave solves L11 x = e_c (forward substitution, L11 read as LDS broadcasts);
+//   II.  the tiles below the diagonal are scaled by their row's diagonal inverse, Lt_ik = W_ii L_ik (MFMA);
+//   III. block diagonal d = 1, 2, ..: W_ij = - sum_{k = j}^{i-1} Lt_ik W_kj (MFMA), i - j = d; W_kj, k - j < d, is complete.
+template <int BWn>
+__device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid) {
+    const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
-    for (int kb = 0; kb < nblk; ++kb) {                      // L y = b
-        const int c0 = 16 * kb, r = c0 + i;
-        const bool in = r < n;
-        const double *Lr = L + (in ? r : 0) * ld;
-        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        for (int c = q; c < c0; c += 16) {                   // c0 is a multiple of 16: four independent LDS read pairs per trip
-            acc = fma(Lr[c], x[c], acc);
-            acc1 = fma(Lr[c + 4], x[c + 4], acc1);
-            acc2 = fma(Lr[c + 8], x[c + 8], acc2);
-            acc3 = fma(Lr[c + 12], x[c + 12], acc3);
-        }
-        acc = (acc + acc1) + (acc2 + acc3);
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        double l[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) l[k] = (in && k < i) ? Lr[c0 + k] : 0.0;
-        const double di = in ? dinv[r] : 0.0;
-        double t = in ? b[r] - acc : 0.0, res = 0.0;
+    const int li = lane & 15, kq = lane >> 4;
+    // W'[a][b] for a < b (storage Mx[a * ld + b]), with the diagonal from dinv and zero below; indices >= n act as identity
+    auto wt = [&](int a, int b2) -> double {
+        if (a >= n || b2 >= n) return a == b2 ? 1.0 : 0.0;
+        return a < b2 ? Mx[a * ld + b2] : (a == b2 ? dinv[a] : 0.0);
+    };
+    for (int kb = wave; kb < nblk; kb += BWn) {                       // I
+        const int c0 = 16 * kb;
+        const int nl = n - c0 < 16 ? n - c0 : 16;
+        double x[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const double yj = readlane_d(t * di, j);
-            t = fma(-l[j], yj, t);
-            res = (i == j) ? yj : res;
-        }
-        if (q == 0 && in) x[r] = res;
-    }
-    for (int kb = nblk - 1; kb >= 0; --kb) {                 // L' x = y
-        const int c0 = 16 * kb, r = c0 + i;
-        const bool in = r < n;
-        const double *Lc = L + (in ? r : 0);
-        double acc = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-        int rr = c0 + 16 + q;
-        for (; rr + 12 < n; rr += 16) {
-            acc = fma(Lc[rr * ld], x[rr], acc);
-            acc1 = fma(Lc[(rr + 4) * ld], x[rr + 4], acc1);
-            acc2 = fma(Lc[(rr + 8) * ld], x[rr + 8], acc2);
-            acc3 = fma(Lc[(rr + 12) * ld], x[rr + 12], acc3);
-        }
-        for (; rr < n; rr += 4) acc = fma(Lc[rr * ld], x[rr], acc);
-        acc = (acc + acc1) + (acc2 + acc3);
-        acc += __shfl_xor(acc, 16);
-        acc += __shfl_xor(acc, 32);
-        double l[16];
+            double v = (j == li) ? 1.0 : 0.0;
+            if (j < nl) {
+                const double *lj = Mx + (c0 + j) * ld + c0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) l[k] = (in && k > i && c0 + k < n) ? Lc[(c0 + k) * ld] : 0.0;
-        const double di = in ? dinv[r] : 0.0;
-        double t = in ? x[r] - acc : 0.0, res = 0.0;
-#pragma unroll
-        for (int j = 15; j >= 0; --j) {
-            const double xj = readlane_d(t * di, j);
-            t = fma(-l[j], xj, t);
-            res = (i == j) ? xj : res;
+                for (int k = 0; k < j; ++k) v = fma(-lj[k], x[k], v);
+                v *= dinv[c0 + j];
+            }
+            x[j] = v;
         }
-        if (q == 0 && in) x[r] = res;
+        if (lane < nl) {
+#pragma unroll
+            for (int j = 1; j < 16; ++j)
+                if (j > lane && j < nl) Mx[(c0 + lane) * ld + c0 + j] = x[j];
+        }
     }
-    for (int k = n + lane; k < nfill; k += WAVE) x[k] = 0.0;  // entries n..nfill-1 (padding) are cleared
+    __syncthreads();
+    {                                                                 // II
+        const int ntile = nblk * (nblk - 1) / 2;
+        for (int t = wave; t < ntile; t += BWn) {
+            int ti = 1, rem = t;
+            while (rem >= ti) { rem -= ti; ++ti; }
+            const int tk = rem;                                       // tile (ti, tk), tk < ti
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const int qq = 4 * s4 + kq;
+                const double av = wt(16 * ti + qq, 16 * ti + li);     // W_ii[m = li][q] = W'[q][m]
+                const double bv = (16 * ti + qq < n) ? Mx[(16 * ti + qq) * ld + 16 * tk + li] : 0.0;
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) Mx[(16 * ti + kq + 4 * reg) * ld + 16 * tk + li] = acc[reg];
+        }
+    }
+    __syncthreads();
+    for (int d = 1; d < nblk; ++d) {                                  // III
+        for (int ti = d + wave; ti < nblk; ti += BWn) {
+            const int tj = ti - d;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            for (int tk = tj; tk < ti; ++tk) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    const int qq = 4 * s4 + kq;
+                    const double av = (16 * ti + li < n) ? Mx[(16 * ti + li) * ld + 16 * tk + qq] : 0.0;   // Lt_ik[m][q]
+                    const double bv = wt(16 * tj + li, 16 * tk + qq);                                        // W_kj[q][n] = W'[n][q]
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = 16 * ti + kq + 4 * reg;               // W_ij[row][col] -> W'[col][row]
+                if (row < n) Mx[(16 * tj + li) * ld + row] = -acc[reg];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// x = W' (W b) = (L L')^-1 b with W from block_invert: two matrix-vector products, thread (row, part) with BTn / 128
+// parts per row, partial sums through `parts` (>= 5 * 128 doubles).  b and x may alias.  Entries n..nfill-1 of x are cleared.
+template <int BTn>
+__device__ __forceinline__ void block_inv_solve(const double *Mx, int ld, int n, const double *dinv, const double *b, double *x,
+                                                double *parts, int tid, int nfill = 0) {
+    constexpr int Q = BTn / 128;
+    const int i = tid & 127, q = tid >> 7;
+    double *yv = parts + Q * 128;
+    {
+        double a0 = 0.0, a1 = 0.0;
+        if (i < n) {
+            int k = q;
+            for (; k + Q < i; k += 2 * Q) { a0 = fma(Mx[k * ld + i], b[k], a0); a1 = fma(Mx[(k + Q) * ld + i], b[k + Q], a1); }
+            if (k < i) a0 = fma(Mx[k * ld + i], b[k], a0);
+        }
+        parts[q * 128 + i] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < n) {
+        double v = dinv[tid] * b[tid];
+#pragma unroll
+        for (int p = 0; p < Q; ++p) v += parts[p * 128 + tid];
+        yv[tid] = v;
+    }
+    __syncthreads();
+    {
+        double a0 = 0.0, a1 = 0.0;
+        if (i < n) {
+            const double *row = Mx + i * ld;
+            int k = i + 1 + q;
+            for (; k + Q < n; k += 2 * Q) { a0 = fma(row[k], yv[k], a0); a1 = fma(row[k + Q], yv[k + Q], a1); }
+            if (k < n) a0 = fma(row[k], yv[k], a0);
+        }
+        parts[q * 128 + i] = a0 + a1;
+    }
+    __syncthreads();
+    if (tid < n) {
+        double v = dinv[tid] * yv[tid];
+#pragma unroll
+        for (int p = 0; p < Q; ++p) v += parts[p * 128 + tid];
+        x[tid] = v;
+    } else if (tid < nfill) {
+        x[tid] = 0.0;
+    }
+    __syncthreads();
 }
 
 // Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of workgroup 0, written to qp.dbg
@@ -706,8 +767,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         }
                     }
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
-                    if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, rhsv, dzav, lane, NVP);
-                    __syncthreads();
+                    block_invert<SH::BW>(big, LDM, nv, dinv, tid);
+                    block_inv_solve<BT>(big, LDM, nv, dinv, rhsv, dzav, parts, tid, NVP);
                     BSTAMP(6);
                     // ---- P5: affine step statistics, corrector terms per row
                     double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
@@ -738,8 +799,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     gt_products<T>(Grm, nc, c1_, rs_, parts, tv, uv, tid, bq);
                     if (tid < NVP) cgv[tid] = rhsv[tid] + tv[tid] - smu * uv[tid];
                     __syncthreads();
-                    if (wave == 0) wave_llt_solve(big, LDM, nv, dinv, cgv, dzv, lane, NVP);
-                    __syncthreads();
+                    block_inv_solve<BT>(big, LDM, nv, dinv, cgv, dzv, parts, tid, NVP);
                     BSTAMP(8);
                     // ---- P7: final direction per row, step length
                     double om = (1.0 - aaff) * (1.0 - aaff);
@@ -825,6 +885,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             dmax = block_reduce1<SH::BW, OpMax>(dmax, red, wave, lane);
                             if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
                             if (!block_chol<SH::BW>(S, LDSS, m, dinv, red + 32, tid)) break;
+                            block_invert<SH::BW>(S, LDSS, m, dinv, tid);
                             for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
                                 if (tid < NVP) {
@@ -853,8 +914,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                                     dyv[tid] = gz - h_[r] - gt;
                                 }
                                 __syncthreads();
-                                if (wave == 0) wave_llt_solve(S, LDSS, m, dinv, dyv, dyv, lane);
-                                __syncthreads();
+                                block_inv_solve<BT>(S, LDSS, m, dinv, dyv, dyv, parts, tid);
                                 // zp -= t1 + Hinv G_W' dy ; y += dy
                                 double dzl = 0.0, zl = 1.0;
                                 if (tid < NVP) {
