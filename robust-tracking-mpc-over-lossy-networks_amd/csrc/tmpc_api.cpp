@@ -782,11 +782,11 @@ int tmpc_kernel_ms_total(tmpc_handle *h, float *total_ms, int32_t *launches, int
 }
 
 #ifdef TMPC_STAMPS
-int tmpc_debug_stamps(tmpc_handle *h, int variant, long long *out12) {
+int tmpc_debug_stamps(tmpc_handle *h, int variant, long long *out12 /* [16] */) {
     if (!h || !out12) return TMPC_E_INVALID;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const long long *src = use_block(h, h->v[variant]) ? h->v[variant].db.dbg : h->v[variant].d.dbg;
-    HIP_TRY(h, hipMemcpy(out12, src, 12 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIP_TRY(h, hipMemcpy(out12, src, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return TMPC_OK;
 }
 #endif

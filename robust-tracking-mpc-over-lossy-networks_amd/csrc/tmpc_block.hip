@@ -110,6 +110,47 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
     return (t0 + t1) + (t2 + t3);
 }
 
+// sum_j Hm[j][c] v[j] + sum_k R[idx[k]][c] w[k] for column c = tid (valid for tid < NVP), by all threads: thread
+// (c, part) takes every (BT / NVP)-th term, eight loads in flight, the parts meet in LDS.  Hm (symmetric, [NVP][NVP]) or R
+// (rows of NVP) may be null.  With the columns alone (128 threads, four loads in flight) a 128-variable product costs
+// 32 dependent L2 round trips.
+template <int T>
+__device__ __forceinline__ double column_sums(const double *__restrict__ Hm, const double *v, const double *__restrict__ R, const int *idx,
+                                              const double *w, int m, double *parts, int tid) {
+    constexpr int NVP = BShape<T>::NVP, P = BShape<T>::BT / NVP;
+    const int c = tid % NVP, part = tid / NVP;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (Hm != nullptr) {
+        if constexpr (NVP / P >= 4) {
+#pragma unroll 2
+            for (int j = part; j < NVP; j += 4 * P) {
+                const double h0 = Hm[j * NVP + c], h1 = Hm[(j + P) * NVP + c], h2 = Hm[(j + 2 * P) * NVP + c], h3 = Hm[(j + 3 * P) * NVP + c];
+                a0 = fma(h0, v[j], a0); a1 = fma(h1, v[j + P], a1); a2 = fma(h2, v[j + 2 * P], a2); a3 = fma(h3, v[j + 3 * P], a3);
+            }
+        } else {
+            for (int j = part; j < NVP; j += P) a0 = fma(Hm[j * NVP + c], v[j], a0);
+        }
+    }
+    if (R != nullptr) {
+        int k = part;
+        for (; k + 3 * P < m; k += 4 * P) {
+            const double r0 = R[static_cast<size_t>(idx[k]) * NVP + c], r1 = R[static_cast<size_t>(idx[k + P]) * NVP + c];
+            const double r2 = R[static_cast<size_t>(idx[k + 2 * P]) * NVP + c], r3 = R[static_cast<size_t>(idx[k + 3 * P]) * NVP + c];
+            a0 = fma(r0, w[k], a0); a1 = fma(r1, w[k + P], a1); a2 = fma(r2, w[k + 2 * P], a2); a3 = fma(r3, w[k + 3 * P], a3);
+        }
+        for (; k < m; k += P) a0 = fma(R[static_cast<size_t>(idx[k]) * NVP + c], w[k], a0);
+    }
+    __syncthreads();                       // previous readers of `parts` are done
+    parts[part * NVP + c] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    double sum = 0.0;
+    if (tid < NVP) {
+#pragma unroll
+        for (int p2 = 0; p2 < P; ++p2) sum += parts[p2 * NVP + tid];
+    }
+    return sum;
+}
+
 // out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
 template <int T>
 __device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
@@ -341,6 +382,13 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
     }
 }
 
+#ifdef TMPC_STAMPS
+#define ISTAMP(p) do { if (tph_) { __syncthreads(); long long now_ = __builtin_amdgcn_s_memtime(); tph_[p] += now_ - *tlast_; *tlast_ = now_; } } while (0)
+#define ISTAMP_ARGS , long long *tph_ = nullptr, long long *tlast_ = nullptr
+#else
+#define ISTAMP(p) do { } while (0)
+#define ISTAMP_ARGS
+#endif
 // Blocked right-looking Cholesky of the n x n lower triangle at Mx (LDS, odd row stride ld) by the whole workgroup, 16
 // columns per step:
 //   1. wave 0 factors the 16 x 16 diagonal block in registers (lane i holds row i; the pivot row reaches the other
@@ -351,7 +399,7 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
 // On return the strictly lower triangle of Mx holds L, dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a
 // non-positive pivot.  Rows and columns >= n are never read as data (masked to zero / identity).
 template <int BWn>
-__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid) {
+__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid ISTAMP_ARGS) {
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -388,6 +436,7 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
             if (!good && lane == 0) piv[0] = 0.0;
         }
         __syncthreads();
+        ISTAMP(15);
         if (piv[0] == 0.0) break;
         if (kb + 1 == nblk) break;
         // panel: row r of A21 against L11 (forward substitution along the row)
@@ -408,6 +457,7 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
             for (int k = 0; k < 16; ++k) row[k] = x[k];
         }
         __syncthreads();
+        ISTAMP(3);
         // trailing update of the tiles (ta, tb), tb <= ta, below / right of the panel
         const int mt = nblk - kb - 1, ntile = mt * (mt + 1) / 2, base = c0 + 16;
         for (int t = wave; t < ntile; t += BWn) {
@@ -417,17 +467,19 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
             const int ri = base + 16 * ta + li, rj = base + 16 * tb + li;
             v4d acc;
             double *ct = Mx + (base + 16 * ta + kq) * ld + base + 16 * tb + li;
+            const double *pa = Mx + (ri < n ? ri : 0) * ld + c0 + kq, *pb = Mx + (rj < n ? rj : 0) * ld + c0 + kq;
+            double av[4], bv[4];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) { av[s4] = pa[4 * s4]; bv[s4] = pb[4 * s4]; }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) acc[reg] = ct[4 * reg * ld];
 #pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) {
-                const double av = ri < n ? -Mx[ri * ld + c0 + 4 * s4 + kq] : 0.0;
-                const double bv = rj < n ? Mx[rj * ld + c0 + 4 * s4 + kq] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
+            for (int s4 = 0; s4 < 4; ++s4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ri < n ? -av[s4] : 0.0, rj < n ? bv[s4] : 0.0, acc, 0, 0, 0);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) ct[4 * reg * ld] = acc[reg];
         }
+        ISTAMP(5);
     }
     __syncthreads();
     const bool ok = piv[0] != 0.0;
@@ -443,14 +495,18 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
 //   II.  the tiles below the diagonal are scaled by their row's diagonal inverse, Lt_ik = W_ii L_ik (MFMA);
 //   III. block diagonal d = 1, 2, ..: W_ij = - sum_{k = j}^{i-1} Lt_ik W_kj (MFMA), i - j = d; W_kj, k - j < d, is complete.
 template <int BWn>
-__device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid) {
+__device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid ISTAMP_ARGS) {
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
-    // W'[a][b] for a < b (storage Mx[a * ld + b]), with the diagonal from dinv and zero below; indices >= n act as identity
+    // W'[a][b] for a < b (storage Mx[a * ld + b]), with the diagonal from dinv and zero below; indices >= n act as
+    // identity.  Branch-free: both loads are issued with clamped addresses, the selects follow.
     auto wt = [&](int a, int b2) -> double {
-        if (a >= n || b2 >= n) return a == b2 ? 1.0 : 0.0;
-        return a < b2 ? Mx[a * ld + b2] : (a == b2 ? dinv[a] : 0.0);
+        const bool in = a < n && b2 < n;
+        const int ac = in ? a : 0, bc = in ? b2 : 0;
+        const double up = Mx[ac * ld + bc], dg = dinv[ac];
+        const double v = a < b2 ? up : (a == b2 ? dg : 0.0);
+        return in ? v : (a == b2 ? 1.0 : 0.0);
     };
     for (int kb = wave; kb < nblk; kb += BWn) {                       // I
         const int c0 = 16 * kb;
@@ -474,6 +530,7 @@ __device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const do
         }
     }
     __syncthreads();
+    ISTAMP(12);
     {                                                                 // II
         const int ntile = nblk * (nblk - 1) / 2;
         for (int t = wave; t < ntile; t += BWn) {
@@ -481,30 +538,52 @@ __device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const do
             while (rem >= ti) { rem -= ti; ++ti; }
             const int tk = rem;                                       // tile (ti, tk), tk < ti
             v4d acc = {0.0, 0.0, 0.0, 0.0};
+            double av[4], bv[4];
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 const int qq = 4 * s4 + kq;
-                const double av = wt(16 * ti + qq, 16 * ti + li);     // W_ii[m = li][q] = W'[q][m]
-                const double bv = (16 * ti + qq < n) ? Mx[(16 * ti + qq) * ld + 16 * tk + li] : 0.0;
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                const int rowb = 16 * ti + qq;
+                av[s4] = wt(rowb, 16 * ti + li);                      // W_ii[m = li][q] = W'[q][m]
+                const double lv = Mx[(rowb < n ? rowb : 0) * ld + 16 * tk + li];
+                bv[s4] = rowb < n ? lv : 0.0;
             }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) Mx[(16 * ti + kq + 4 * reg) * ld + 16 * tk + li] = acc[reg];
         }
     }
     __syncthreads();
+    ISTAMP(13);
     for (int d = 1; d < nblk; ++d) {                                  // III
         for (int ti = d + wave; ti < nblk; ti += BWn) {
             const int tj = ti - d;
             v4d acc = {0.0, 0.0, 0.0, 0.0};
+            const int rowa = 16 * ti + li;
+            const bool aok = rowa < n;                                // (only the last block row can be partial)
+            const double *arow = Mx + (aok ? rowa : 0) * ld + kq;     // Lt_ik[m = li][q] at arow[16 k + q]
+            const double *brow = Mx + (16 * tj + li) * ld + kq;       // W_kj[q][n = li] = W'[n][q] at brow[16 k + q], k > j
+            double av[4], bv[4], an[4], bn[4];
+            const double dj = dinv[16 * tj + li];
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {                          // k = j: the diagonal block W_jj (lower triangular)
+                const int qq = 4 * s4 + kq;
+                const double lv = arow[16 * tj + 4 * s4], up = brow[16 * tj + 4 * s4];
+                av[s4] = aok ? lv : 0.0;
+                bv[s4] = li < qq ? up : (li == qq ? dj : 0.0);
+            }
             for (int tk = tj; tk < ti; ++tk) {
+                const int tn = tk + 1 < ti ? tk + 1 : ti - 1;         // the next product's operands while this one runs
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    const int qq = 4 * s4 + kq;
-                    const double av = (16 * ti + li < n) ? Mx[(16 * ti + li) * ld + 16 * tk + qq] : 0.0;   // Lt_ik[m][q]
-                    const double bv = wt(16 * tj + li, 16 * tk + qq);                                        // W_kj[q][n] = W'[n][q]
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    const double lv = arow[16 * tn + 4 * s4];
+                    an[s4] = aok ? lv : 0.0;
+                    bn[s4] = brow[16 * tn + 4 * s4];
                 }
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4], bv[s4], acc, 0, 0, 0);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) { av[s4] = an[s4]; bv[s4] = bn[s4]; }
             }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
@@ -651,11 +730,9 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
         }
         __syncthreads();
         // z = -Hinv q (Hinv symmetric: column read = coalesced)
-        if (tid < NVP) {
-            double v = 0.0;
-            #pragma unroll 4
-            for (int j = 0; j < NVP; ++j) v -= qp.Hinv[j * NVP + tid] * qv[j];
-            zv[tid] = v;
+        {
+            const double v = column_sums<T>(qp.Hinv, qv, nullptr, nullptr, nullptr, 0, parts, tid);
+            if (tid < NVP) zv[tid] = -v;
         }
         __syncthreads();
         double smin_l = INFINITY;
@@ -712,11 +789,9 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     const double mu = gap / ncd;
                     BSTAMP(1);
                     // ---- P2: cost gradient, G'lam, G'(d.rp)
-                    if (tid < NVP) {
-                        double v = qv[tid];
-                        #pragma unroll 4
-            for (int j = 0; j < NVP; ++j) v += qp.Hs[j * NVP + tid] * zv[j];
-                        cgv[tid] = v;
+                    {
+                        const double v = column_sums<T>(qp.Hs, zv, nullptr, nullptr, nullptr, 0, parts, tid);
+                        if (tid < NVP) cgv[tid] = qv[tid] + v;
                     }
                     gt_products<T>(Grm, nc, lam_, v1_, parts, glv, tv, tid, bq);
                     double rdn = 0.0, obj = 0.0, gln = 0.0;
@@ -754,7 +829,11 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         gdg_all<T>(Grm, d_, bq, nsteps, big, wave, lane);
                         zblock_accumulate<T>(Grm, d_, bq, big, parts, tid);
                         BSTAMP(4);
+#ifdef TMPC_STAMPS
+                        spd = block_chol<SH::BW>(big, LDM, nv, dinv, red + 32, tid, tph, &tlast);
+#else
                         spd = block_chol<SH::BW>(big, LDM, nv, dinv, red + 32, tid);
+#endif
                         BSTAMP(5);
                         if (!spd) {
                             // 1e-13 * trace(M), as the oracle does: trace(G'DG) = sum of the weights (unit rows)
@@ -767,7 +846,12 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         }
                     }
                     if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
+#ifdef TMPC_STAMPS
+                    block_invert<SH::BW>(big, LDM, nv, dinv, tid, tph, &tlast);
+                    BSTAMP(14);
+#else
                     block_invert<SH::BW>(big, LDM, nv, dinv, tid);
+#endif
                     block_inv_solve<BT>(big, LDM, nv, dinv, rhsv, dzav, parts, tid, NVP);
                     BSTAMP(6);
                     // ---- P5: affine step statistics, corrector terms per row
@@ -861,12 +945,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         const int m = ibc[0];
                         if (m > WCAP) break;
                         if (m == 0) {
-                            if (tid < NVP) {
-                                double v = 0.0;
-                                #pragma unroll 4
-            for (int j = 0; j < NVP; ++j) v -= qp.Hinv[j * NVP + tid] * qv[j];
-                                zpv[tid] = v;
-                            }
+                            const double v = column_sums<T>(qp.Hinv, qv, nullptr, nullptr, nullptr, 0, parts, tid);
+                            if (tid < NVP) zpv[tid] = -v;
                             __syncthreads();
                         } else {
                             // S = G_W Hinv G_W' (lower triangle): rows of G Hinv (precomputed) . rows of G
@@ -888,20 +968,15 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             block_invert<SH::BW>(S, LDSS, m, dinv, tid);
                             for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
-                                if (tid < NVP) {
-                                    double v = qv[tid];
-                                    #pragma unroll 4
-            for (int j = 0; j < NVP; ++j) v += qp.Hs[j * NVP + tid] * zpv[j];
-                                    for (int k = 0; k < m; ++k) v += Grm[static_cast<size_t>(Widx[k]) * NVP + tid] * yv[k];
-                                    tv[tid] = v;
+                                {
+                                    const double v = column_sums<T>(qp.Hs, zpv, Grm, Widx, yv, m, parts, tid);
+                                    if (tid < NVP) tv[tid] = qv[tid] + v;
                                 }
                                 __syncthreads();
                                 // t1 = Hinv r1
-                                if (tid < NVP) {
-                                    double v = 0.0;
-                                    #pragma unroll 4
-            for (int j = 0; j < NVP; ++j) v += qp.Hinv[j * NVP + tid] * tv[j];
-                                    uv[tid] = v;
+                                {
+                                    const double v = column_sums<T>(qp.Hinv, tv, nullptr, nullptr, nullptr, 0, parts, tid);
+                                    if (tid < NVP) uv[tid] = v;
                                 }
                                 __syncthreads();
                                 // dy rhs: (G_W zp - h_W) - G_W t1
@@ -909,17 +984,17 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                                     const int r = Widx[tid];
                                     const double *g = Grm + static_cast<size_t>(r) * NVP;
                                     double gz = 0.0, gt = 0.0;
-                                    #pragma unroll 4
-            for (int j = 0; j < NVP; ++j) { gz = fma(g[j], zpv[j], gz); gt = fma(g[j], uv[j], gt); }
+#pragma unroll 8
+                                    for (int j = 0; j < NVP; ++j) { gz = fma(g[j], zpv[j], gz); gt = fma(g[j], uv[j], gt); }
                                     dyv[tid] = gz - h_[r] - gt;
                                 }
                                 __syncthreads();
                                 block_inv_solve<BT>(S, LDSS, m, dinv, dyv, dyv, parts, tid);
                                 // zp -= t1 + Hinv G_W' dy ; y += dy
                                 double dzl = 0.0, zl = 1.0;
+                                const double ghd = column_sums<T>(nullptr, nullptr, GHrm, Widx, dyv, m, parts, tid);
                                 if (tid < NVP) {
-                                    double v = uv[tid];
-                                    for (int k = 0; k < m; ++k) v += GHrm[static_cast<size_t>(Widx[k]) * NVP + tid] * dyv[k];
+                                    const double v = uv[tid] + ghd;
                                     const double zn2 = zpv[tid] - v;
                                     zpv[tid] = zn2;
                                     dzl = fabs(v);
@@ -1031,7 +1106,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
         if (tid == 0) { status[b] = st; iters[b] = it_done; }
 #ifdef TMPC_STAMPS
         BSTAMP(11);
-        if (blockIdx.x == 0 && tid == 0 && qp.dbg && it_done > 0) { for (int p_ = 0; p_ < 12; ++p_) qp.dbg[p_] = tph[p_]; qp.dbg[12] = it_done; }
+        if (blockIdx.x == 0 && tid == 0 && qp.dbg && it_done > 0) { for (int p_ = 0; p_ < 16; ++p_) qp.dbg[p_] = tph[p_]; }
 #endif
     }
 }

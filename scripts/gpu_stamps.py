@@ -14,7 +14,7 @@ def run(name, N, fixed, X, R, B):
     L.tmpc_debug_stamps.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_longlong)]
     for _ in range(2):
         o = mpc._solve(X[:B], R[:B], want_traj=False)
-    buf = (C.c_longlong * 12)()
+    buf = (C.c_longlong * 16)()
     L.tmpc_debug_stamps(h.ptr, 0, buf)
     t = np.array(buf[:10], dtype=float)
     it = max(int(o["iters"][0]), 1)
