@@ -115,7 +115,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
 // (rows of NVP) may be null.  With the columns alone (128 threads, four loads in flight) a 128-variable product costs
 // 32 dependent L2 round trips.
 template <int T>
-__device__ __forceinline__ double column_sums(const double *__restrict__ Hm, const double *v, const double *__restrict__ R, const int *idx,
+__device__ __noinline__ double column_sums(const double *__restrict__ Hm, const double *v, const double *__restrict__ R, const int *idx,
                                               const double *w, int m, double *parts, int tid) {
     constexpr int NVP = BShape<T>::NVP, P = BShape<T>::BT / NVP;
     const int c = tid % NVP, part = tid / NVP;
@@ -153,7 +153,7 @@ __device__ __forceinline__ double column_sums(const double *__restrict__ Hm, con
 
 // out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
 template <int T>
-__device__ __forceinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
+__device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
                                             double *parts, double *out_a, double *out_b, int tid, const BlockQP &bq) {
     constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS, BT = BShape<T>::BT, NV2 = NVP / 2;
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -399,7 +399,7 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
 // On return the strictly lower triangle of Mx holds L, dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a
 // non-positive pivot.  Rows and columns >= n are never read as data (masked to zero / identity).
 template <int BWn>
-__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid ISTAMP_ARGS) {
+__device__ __noinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid ISTAMP_ARGS) {
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -495,7 +495,7 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
 //   II.  the tiles below the diagonal are scaled by their row's diagonal inverse, Lt_ik = W_ii L_ik (MFMA);
 //   III. block diagonal d = 1, 2, ..: W_ij = - sum_{k = j}^{i-1} Lt_ik W_kj (MFMA), i - j = d; W_kj, k - j < d, is complete.
 template <int BWn>
-__device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid ISTAMP_ARGS) {
+__device__ __noinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid ISTAMP_ARGS) {
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -598,7 +598,7 @@ __device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const do
 // x = W' (W b) = (L L')^-1 b with W from block_invert: two matrix-vector products, thread (row, part) with BTn / 128
 // parts per row, partial sums through `parts` (>= 5 * 128 doubles).  b and x may alias.  Entries n..nfill-1 of x are cleared.
 template <int BTn>
-__device__ __forceinline__ void block_inv_solve(const double *Mx, int ld, int n, const double *dinv, const double *b, double *x,
+__device__ __noinline__ void block_inv_solve(const double *Mx, int ld, int n, const double *dinv, const double *b, double *x,
                                                 double *parts, int tid, int nfill = 0) {
     constexpr int Q = BTn / 128;
     const int i = tid & 127, q = tid >> 7;
