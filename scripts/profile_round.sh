@@ -3,6 +3,7 @@
 # Usage (on the GPU box): bash scripts/profile_round.sh <tag>
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+rm -rf gpurun_out/prof_$tag* gpurun_out/pmc_${tag}_*      # (the merge back keeps older files of the same name otherwise)
 BENCH="python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-closed-loop --no-extras"
 # ---- the bench kernel (BASELINE configs[1])
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $BENCH > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
