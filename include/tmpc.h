@@ -222,6 +222,19 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
 int tmpc_mc_set_warm_start(tmpc_handle *h, int on);
 
 /*
+ * Per-solve computation times -- what the reference's controllers keep in _computational_times and the scripts print as
+ * max / quantiles / median (TubeTrackingMPC.py:205, 242-243; results_linear_system.py:305-315).  On the device an MPC solve
+ * is one instance of a batched launch; with tmpc_set_solve_timing(on) every instance records the time from the moment its
+ * wavefront / workgroup picks it up to the moment its outputs are written, in ticks of the GPU's constant 100 MHz counter
+ * (s_memrealtime: 1 tick = 10 ns).  tmpc_get_solve_ticks copies out the B tick counts of the last tmpc_solve_batch /
+ * tmpc_solve_batch_device call (instances a variant selector skipped: 0); after a tmpc_mc_run, tmpc_mc_get_solve_ticks
+ * gives per trajectory the sum and the maximum over its T solves (either pointer may be NULL).  Off by default.
+ */
+int tmpc_set_solve_timing(tmpc_handle *h, int on);
+int tmpc_get_solve_ticks(tmpc_handle *h, int64_t B, int64_t *ticks);
+int tmpc_mc_get_solve_ticks(tmpc_handle *h, int64_t B, int64_t *ticks_sum, int64_t *ticks_max);
+
+/*
  * Sample trajectory of tmpc_mc_run -- what the scripts keep for their plots (x_traj, x_nom_traj of one run per loss rate,
  * results_linear_system.py:298-301).  tmpc_mc_set_capture(index >= 0) makes the following runs record trajectory `index`
  * (-1: off); after a run tmpc_mc_get_capture copies out, for t = 0 .. T-1, the plant state x_t, the nominal state the tube

@@ -148,7 +148,7 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         return d
 
     # ------------------------------------------------------------------ online
-    def _solve(self, x_init, ref, variant=None, want_traj: bool = True):
+    def _solve(self, x_init, ref, variant=None, want_traj: bool = True, timing: bool = False):
         from . import _native
         if self._handle is None:
             raise RuntimeError("setup_optimization() has not been called")
@@ -156,8 +156,10 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         r = np.ascontiguousarray(np.asarray(ref, dtype=np.float64).reshape(-1, self._nx))
         if r.shape[0] == 1 and x.shape[0] > 1:
             r = np.ascontiguousarray(np.broadcast_to(r, x.shape))
-        out = _native.solve_batch(self._handle, x, r, variant, want_traj)
+        out = _native.solve_batch(self._handle, x, r, variant, want_traj, timing=timing)
         self.last_status, self.last_iters = out["status"], out["iters"]
+        if timing:
+            self.last_solve_time = out["solve_time"]       # seconds per instance on the device (tmpc_set_solve_timing)
         return out
 
     def solve_optimization_problem(self, x_init, ref):
@@ -212,19 +214,24 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         return np.ascontiguousarray(U.transpose(0, 2, 1)), out["x_nom0"], out["status"]
 
     def run_closed_loop(self, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False, plant=None, warm_start: bool = False,
-                        capture=None) -> dict:
+                        capture=None, timing: bool = False) -> dict:
         """The lossy-network closed loop of the reference's Monte-Carlo scripts (results_linear_system.py:209-291)
         for a batch of trajectories, resident on the device (include/tmpc.h: tmpc_mc_run): every time step is one
         solve launch plus one state-machine launch, nothing returns to the host in between.  warm_start: every solve first
         tries the working set of the trajectory's previous solve in the exact refinement (same results, fewer iterations);
-        capture: index of one trajectory whose x_t / x_nom_t / u_t are returned (the scripts' sample run, :298-301)."""
+        capture: index of one trajectory whose x_t / x_nom_t / u_t are returned (the scripts' sample run, :298-301).
+        timing: per trajectory the mean / maximum device time of a solve (solve_time_mean, solve_time_max, seconds); the
+        means are also appended to get_computational_times(), the list the scripts take their quantiles of (:305-315)."""
         from . import _native
         if self._handle is None:
             raise RuntimeError("setup_optimization() has not been called")
         _native.mc_set_plant(self._handle, plant)        # None: the linear model; 'cartpole': the nonlinear cart-pole (RK4, 500 Hz)
         _native.mc_set_actuator(self._handle, self._smart_actuator)
-        return _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
-                              extended=extended, warm_start=warm_start, capture=capture)
+        out = _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
+                             extended=extended, warm_start=warm_start, capture=capture, timing=timing)
+        if timing:
+            self._computational_times.extend(out["solve_time_mean"].tolist())
+        return out
 
     # ------------------------------------------------------------------ accessors
     def set_ancillary_controller_gain(self, K_ancillary):

@@ -92,6 +92,12 @@ def lib():
         L.tmpc_mc_set_capture.restype = C.c_int
         L.tmpc_mc_get_capture.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.tmpc_mc_get_capture.restype = C.c_int
+        L.tmpc_set_solve_timing.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_set_solve_timing.restype = C.c_int
+        L.tmpc_get_solve_ticks.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.tmpc_get_solve_ticks.restype = C.c_int
+        L.tmpc_mc_get_solve_ticks.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.tmpc_mc_get_solve_ticks.restype = C.c_int
         L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_warm_start.restype = C.c_int
         L.tmpc_mc_run.restype = C.c_int
@@ -201,9 +207,15 @@ def get_condensed(h: Handle, variant: int = 0) -> dict:
     return out
 
 
-def solve_batch(h: Handle, x, r, variant=None, want_traj: bool = True) -> dict:
-    """Host-pointer entry (tmpc_solve_batch): numpy in, numpy out."""
+TICK_SECONDS = 1e-8      # s_memrealtime: constant 100 MHz (include/tmpc.h, tmpc_set_solve_timing)
+
+
+def solve_batch(h: Handle, x, r, variant=None, want_traj: bool = True, timing: bool = False) -> dict:
+    """Host-pointer entry (tmpc_solve_batch): numpy in, numpy out.  timing: also `solve_time` (B,), the seconds every
+    instance spent in its wavefront / workgroup (tmpc_set_solve_timing)."""
     B = x.shape[0]
+    if lib().tmpc_set_solve_timing(h.ptr, int(bool(timing))) != 0:
+        raise RuntimeError(h.error())
     nx, nu, N = h.nx, h.nu, h.N
     out = dict(u_nom=np.empty((B, N, nu)), x_nom0=np.empty((B, nx)), xu_ss=np.empty((B, nx + nu)),
                x_nom=np.empty((B, N + 1, nx)) if want_traj else None,
@@ -220,6 +232,11 @@ def solve_batch(h: Handle, x, r, variant=None, want_traj: bool = True) -> dict:
         raise RuntimeError(f"tmpc_solve_batch failed ({rc}): {h.error()}")
     out["x_ss"] = out["xu_ss"][:, :nx]
     out["u_ss"] = out["xu_ss"][:, nx:]
+    if timing:
+        ticks = np.empty(B, np.int64)
+        if lib().tmpc_get_solve_ticks(h.ptr, B, ticks.ctypes.data) != 0:
+            raise RuntimeError(h.error())
+        out["solve_time"] = ticks * TICK_SECONDS
     return out
 
 
@@ -293,10 +310,13 @@ def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
 
 
 def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False,
-           capture=None) -> dict:
+           capture=None, timing: bool = False) -> dict:
     """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device.
     warm_start: tmpc_mc_set_warm_start for this call; capture: index of a trajectory to record (tmpc_mc_set_capture) ->
-    x_traj (T, nx), x_nom_traj (T, nx), u_traj (T, nu) in the result."""
+    x_traj (T, nx), x_nom_traj (T, nx), u_traj (T, nu) in the result; timing: per trajectory the mean and the maximum
+    time of its T solves in seconds (solve_time_mean, solve_time_max; tmpc_set_solve_timing)."""
+    if lib().tmpc_set_solve_timing(h.ptr, int(bool(timing))) != 0:
+        raise RuntimeError(h.error())
     if lib().tmpc_mc_set_warm_start(h.ptr, int(bool(warm_start))) != 0:
         raise RuntimeError(h.error())
     if lib().tmpc_mc_set_capture(h.ptr, -1 if capture is None else int(capture)) != 0:
@@ -324,6 +344,11 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
         out["x_traj"], out["x_nom_traj"], out["u_traj"] = np.empty((T, h.nx)), np.empty((T, h.nx)), np.empty((T, h.nu))
         if lib().tmpc_mc_get_capture(h.ptr, T, ptr(out["x_traj"]), ptr(out["x_nom_traj"]), ptr(out["u_traj"])) != 0:
             raise RuntimeError(h.error())
+    if timing:
+        tsum, tmax = np.empty(B, np.int64), np.empty(B, np.int64)
+        if lib().tmpc_mc_get_solve_ticks(h.ptr, B, tsum.ctypes.data, tmax.ctypes.data) != 0:
+            raise RuntimeError(h.error())
+        out["solve_time_mean"], out["solve_time_max"] = tsum * (TICK_SECONDS / max(T, 1)), tmax * TICK_SECONDS
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
     out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve

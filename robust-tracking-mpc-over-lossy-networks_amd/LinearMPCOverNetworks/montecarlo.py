@@ -229,12 +229,14 @@ def plant_callable(plant):
 
 
 def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
-             extended: bool = False, device=None, on_device: bool = False, plant=None, warm_start: bool = False):
+             extended: bool = False, device=None, on_device: bool = False, plant=None, warm_start: bool = False,
+             timing: bool = False):
     """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
     trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
     shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
     Returns (table (n_total, 3) = [tracking error, tube violations, non-optimal solves], p_index (n_total,)),
-    identical on every rank."""
+    identical on every rank.  timing (device loop only): two more columns, the mean and the maximum device time of a
+    trajectory's solves in seconds -- the computational times results_linear_system.py:305-315 reports."""
     import torch
     p_loss = np.asarray(p_loss, dtype=np.float64)
     pi, _ = trajectory_table(p_loss, n_mc)
@@ -243,7 +245,8 @@ def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240
     th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
     ref = np.broadcast_to(np.asarray(ref, dtype=np.float64), (T,))
     if on_device:        # state machines on the GPU as well (tmpc_mc_run); otherwise the host loop around determine_packets
-        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended, plant=plant, warm_start=warm_start)
+        out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended, plant=plant, warm_start=warm_start,
+                                  timing=timing)
     elif getattr(mpc, "_smart_actuator", False):       # TrackingMPC: the comparator's loop (results_linear_system.py:262-287)
         out = run_remote_tracking_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(), mpc._N,
                                       p_loss[pi[lo:hi]], ref, th, ga, w)
@@ -252,7 +255,10 @@ def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240
         out = run_remote_tube_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(),
                                   mpc.get_ancillary_controller_gain(), mpc._N, mpc._Z, p_loss[pi[lo:hi]], ref, th, ga, w,
                                   extended=extended, plant=None if plant is None else plant_callable(plant))
-    local = torch.tensor(np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]], dtype=torch.float64)
+    cols = [out["tracking_error"], out["tube_violations"], out["not_optimal"]]
+    if timing and on_device:
+        cols += [out["solve_time_mean"], out["solve_time_max"]]
+    local = torch.tensor(np.column_stack(cols), dtype=torch.float64)
     if device is not None:
         local = local.to(device)
     table = gather_statistics(local, n_total, rank, world)

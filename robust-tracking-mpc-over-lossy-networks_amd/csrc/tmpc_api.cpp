@@ -65,6 +65,12 @@ struct tmpc_handle {
     double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
     uint8_t *d_var = nullptr;
     int32_t *d_st = nullptr, *d_it = nullptr;
+    // per-solve durations (tmpc_set_solve_timing): one tick count per instance of the last call
+    int want_ticks = 0;
+    int64_t ticks_cap = 0, ticks_n = 0;
+    long long *d_ticks = nullptr;
+    long long *mc_tick_sum = nullptr, *mc_tick_max = nullptr;      // inside mc_arena, of the last tmpc_mc_run
+    int64_t mc_tick_B = 0;
     std::string err;
 };
 
@@ -105,6 +111,7 @@ int upload_common(tmpc_handle *h, Variant &v, const tmpc_problem &p, tmpc::Devic
     d.tol = p.tol > 0 ? p.tol : 1e-7;
     d.always_infeasible = c.always_infeasible ? 1 : 0;
     d.dbg = nullptr;
+    d.ticks = nullptr;
     int rc;
     if ((rc = upload(h, v, Hs.data(), Hs.size(), &d.Hs))) return rc;
     if ((rc = upload(h, v, Hinv.data(), Hinv.size(), &d.Hinv))) return rc;
@@ -382,9 +389,24 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     if (variant != nullptr)
         HIP_TRY(h, tmpc::launch_mark_invalid_variants(variant, h->nvariants, B, h->nx, h->nu, h->N, u_nom, x_nom0, xu_ss, x_nom, status,
                                                       iters, h->stream));
+    long long *ticks = nullptr;
+    if (h->want_ticks) {
+        if (B > h->ticks_cap) {
+            HIP_TRY(h, hipStreamSynchronize(h->stream));
+            if (h->d_ticks) (void)hipFree(h->d_ticks);
+            h->d_ticks = nullptr; h->ticks_cap = 0;
+            HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_ticks), static_cast<size_t>(B) * sizeof(long long)));
+            h->ticks_cap = B;
+        }
+        ticks = h->d_ticks;
+        h->ticks_n = B;
+        HIP_TRY(h, hipMemsetAsync(ticks, 0, static_cast<size_t>(B) * sizeof(long long), h->stream));
+    }
     for (int k = 0; k < h->nvariants; ++k) {
         if (k == 1 && variant == nullptr) break;        // no per-instance selector: everything is variant 0
         Variant &v = h->v[k];
+        v.d.ticks = ticks;
+        v.db.ticks = ticks;
         if (use_block(h, v)) {
             int rcw = ensure_block_ws(h);
             if (rcw) return rcw;
@@ -506,7 +528,7 @@ void tmpc_destroy(tmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
     {
-        void *wsp[] = {h->blk_ws, h->mc_arena, h->wc.ring};
+        void *wsp[] = {h->blk_ws, h->mc_arena, h->wc.ring, h->d_ticks};
         for (void *q2 : wsp) if (q2) (void)hipFree(q2);
     }
     for (int k = 0; k < 2; ++k)
@@ -624,6 +646,33 @@ int tmpc_mc_get_capture(tmpc_handle *h, int32_t T, double *x_traj, double *x_nom
     return TMPC_OK;
 }
 
+int tmpc_set_solve_timing(tmpc_handle *h, int on) {
+    if (!h) return TMPC_E_INVALID;
+    h->want_ticks = on ? 1 : 0;
+    if (!on) h->ticks_n = 0;
+    return TMPC_OK;
+}
+
+int tmpc_get_solve_ticks(tmpc_handle *h, int64_t B, int64_t *ticks) {
+    if (!h || !ticks) return TMPC_E_INVALID;
+    if (!h->want_ticks || B != h->ticks_n || !h->d_ticks) { h->err = "tmpc_get_solve_ticks: no solve of this batch size was timed (tmpc_set_solve_timing)"; return TMPC_E_INVALID; }
+    static_assert(sizeof(long long) == sizeof(int64_t), "tick counts are 64-bit");
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(ticks, h->d_ticks, static_cast<size_t>(B) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
+int tmpc_mc_get_solve_ticks(tmpc_handle *h, int64_t B, int64_t *ticks_sum, int64_t *ticks_max) {
+    if (!h) return TMPC_E_INVALID;
+    if (!h->mc_tick_sum || B != h->mc_tick_B) { h->err = "tmpc_mc_get_solve_ticks: the last tmpc_mc_run was not timed (tmpc_set_solve_timing) or had another batch size"; return TMPC_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if (ticks_sum) HIP_TRY(h, hipMemcpy(ticks_sum, h->mc_tick_sum, static_cast<size_t>(B) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (ticks_max) HIP_TRY(h, hipMemcpy(ticks_max, h->mc_tick_max, static_cast<size_t>(B) * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
 int tmpc_mc_set_warm_start(tmpc_handle *h, int on) {
     if (!h) return TMPC_E_INVALID;
     h->mc_warm = on ? 1 : 0;
@@ -647,7 +696,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
     const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + 2 * t_ + t_ * nx)) +
-                        8 * b * (6 * nx + (N + 1) * nu + nu + 2) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
+                        8 * b * (6 * nx + (N + 1) * nu + nu + 4) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
     if (need > h->mc_arena_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mc_arena) (void)hipFree(h->mc_arena);
@@ -720,6 +769,15 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             h->mc_cap_dev = st.cap;
             h->mc_cap_T = T;
         }
+        h->mc_tick_sum = h->mc_tick_max = nullptr;
+        h->mc_tick_B = 0;
+        if (h->want_ticks) {
+            if ((r2 = dalloc(b * 8, reinterpret_cast<void **>(&st.tick_sum)))) return r2;
+            if ((r2 = dalloc(b * 8, reinterpret_cast<void **>(&st.tick_max)))) return r2;
+            HIP_TRY(h, hipMemsetAsync(st.tick_sum, 0, b * 8, h->stream));
+            HIP_TRY(h, hipMemsetAsync(st.tick_max, 0, b * 8, h->stream));
+            h->mc_tick_sum = st.tick_sum; h->mc_tick_max = st.tick_max; h->mc_tick_B = B;
+        }
         // warm start: one working-set record per trajectory and variant (row ids are per variant), updated in place by the
         // solve kernel; m = 0 (the memset) means "nothing to start from"
         int32_t *ws[2] = {nullptr, nullptr};
@@ -733,6 +791,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             HIP_TRY(h, tmpc::launch_mc_pre(m, st, t, B, ref[t], h->stream));
             int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it, ws);
             if (r3) return r3;
+            st.ticks = h->want_ticks ? h->d_ticks : nullptr;       // (allocated by the first enqueue)
             HIP_TRY(h, tmpc::launch_mc_post(m, st, t, T, B, ref[t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, h->stream));
             HIP_TRY(h, tmpc::launch_mc_tube(m, st, B, h->stream));
         }

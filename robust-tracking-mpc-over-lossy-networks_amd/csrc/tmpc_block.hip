@@ -700,6 +700,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
         __syncthreads();
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
+        const long long t_begin = qp.ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
 #ifdef TMPC_STAMPS
         long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_amdgcn_s_memtime();
@@ -1104,6 +1105,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
             }
         }
         if (tid == 0) { status[b] = st; iters[b] = it_done; }
+        if (qp.ticks && tid == 0) qp.ticks[b] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()) - t_begin;
 #ifdef TMPC_STAMPS
         BSTAMP(11);
         if (blockIdx.x == 0 && tid == 0 && qp.dbg && it_done > 0) { for (int p_ = 0; p_ < 16; ++p_) qp.dbg[p_] = tph[p_]; }

@@ -47,6 +47,7 @@ struct DeviceQP {
     const double *A;      // [nx][nx]
     const double *B;      // [nx][nu]
     long long *dbg;       // diagnostic builds only (TMPC_STAMPS); nullptr otherwise
+    long long *ticks;     // [B] or nullptr: time the instance spent in its wave / workgroup, in s_memrealtime ticks (10 ns)
 };
 
 // Block path (tmpc_block.hip): all rows dense, row order of Condensed::Gs, nv padded to 16 * tiles
@@ -115,6 +116,8 @@ struct McState {                         // all [trajectory]-major device arrays
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
     uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
+    const long long *ticks;                   // per-solve durations of the step just solved, or nullptr                [B]
+    long long *tick_sum, *tick_max;           // their sum and maximum along the trajectory (with ticks)                 [B]
     long long cap_index;                      // trajectory whose states are recorded (-1: none)
     double *cap;                              // [T][2 nx + nu]: x_t, the nominal state the tube check uses, u_t
 };

@@ -431,6 +431,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         wave_lds_fence();
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
+        const long long t_begin = qp.ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
 #ifdef TMPC_STAMPS
         long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_amdgcn_s_memtime();
@@ -1214,6 +1215,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             }
         }
         if (lane == 0) { status[b] = st; iters[b] = it_done; }
+        if (qp.ticks && lane == 0) qp.ticks[b] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()) - t_begin;
 #ifdef TMPC_STAMPS
         STAMP(8);
         if (b == 0 && lane == 0 && qp.dbg) { for (int p_ = 0; p_ < 12; ++p_) qp.dbg[p_] = tph[p_]; }

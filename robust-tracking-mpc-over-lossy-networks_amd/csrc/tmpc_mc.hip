@@ -60,7 +60,12 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     const int stat = status[b];
     const bool bad = stat >= 2;
     if (stat != 0) st.not_optimal[b] += 1;
-    st.iters_sum[b] += iters[b];                                                          // results_linear_system.py:305-315 report solve effort
+    st.iters_sum[b] += iters[b];
+    if (st.ticks) {
+        const long long tk = st.ticks[b];
+        st.tick_sum[b] += tk;
+        if (tk > st.tick_max[b]) st.tick_max[b] = tk;
+    }                                                          // results_linear_system.py:305-315 report solve effort
     if (bad) theta = 0;            // a failed solve sends nothing (the reference's tube branch would raise here)
     if (m.smart && bad) {          // R-MPC branch: the trajectory ends here (:268-270), its tracking error is NaN (:297)
         st.dead[b] = 1;

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--rmpc", action="store_true", help="the non-robust comparator TrackingMPC (results_linear_system.py:132-140, 262-287) "
                                                         "instead of the tube MPC; reports the infeasible runs per loss rate (:268-270)")
     ap.add_argument("--warm-start", action="store_true", help="tmpc_mc_set_warm_start: previous working set first")
+    ap.add_argument("--timing", action="store_true", help="per-solve device times (tmpc_set_solve_timing): the max / quantiles / median "
+                                                          "results_linear_system.py:305-315 prints")
     ap.add_argument("--host-loop", action="store_true", help="state machines in numpy on the host instead of on the device")
     ap.add_argument("--reference-streams", action="store_true",
                     help="replay the reference's own random streams (seeds 679/347/124 consumed in its loop order, "
@@ -48,12 +50,14 @@ def main():
         if world != 1:
             raise SystemExit("--reference-streams keeps the reference's draw order and cannot be sharded")
         pl, th, ga, wd = montecarlo.draw_realisations_reference_order(p_loss, args.n_mc, args.T, model["w_bound"])
-        out = mpc.run_closed_loop(pl, np.full(args.T, args.ref), th, ga, wd, extended=args.extended, warm_start=args.warm_start)
+        out = mpc.run_closed_loop(pl, np.full(args.T, args.ref), th, ga, wd, extended=args.extended, warm_start=args.warm_start, timing=args.timing)
         table = np.c_[out["tracking_error"], out["tube_violations"], out["not_optimal"]]
+        if args.timing:
+            table = np.c_[table, out["solve_time_mean"], out["solve_time_max"]]
         pi = np.repeat(np.arange(len(p_loss)), args.n_mc)
     else:
         table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
-                                        extended=args.extended, device=device, on_device=not args.host_loop, warm_start=args.warm_start)
+                                        extended=args.extended, device=device, on_device=not args.host_loop, warm_start=args.warm_start, timing=args.timing and not args.host_loop)
     dt = time.time() - t0
     if rank == 0:
         n = len(pi)
@@ -65,6 +69,11 @@ def main():
             dead = int(np.isnan(te).sum())                       # R-MPC: a run whose QP became infeasible stops (NaN tracking error, :297)
             mean_te = float(np.nanmean(te)) if dead < m.sum() else float("nan")
             print(f"{p:5.1f}   {mean_te:.6f}            {int(table[m, 1].sum()):6d}            {int(table[m, 2].sum()):6d}            {dead:6d}")
+        if args.timing and table.shape[1] >= 5:                      # results_linear_system.py:305-315, in milliseconds
+            mean_ms, max_ms = 1e3 * table[:, 3], 1e3 * table[:, 4]
+            print(f"device time per MPC solve (one instance of a batched launch), {n} trajectory means: max of all solves {max_ms.max():.3f} ms, "
+                  f"95% quantile {np.quantile(mean_ms, 0.95):.3f}, 90% {np.quantile(mean_ms, 0.9):.3f}, 75% {np.quantile(mean_ms, 0.75):.3f}, "
+                  f"median {np.median(mean_ms):.3f}, mean {mean_ms.mean():.3f} ms")
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -1,6 +1,8 @@
 """Closed loop over a lossy network (results_linear_system.py:209-291) driven by the batched state
 machines.  The CPU test uses the oracle as the solver (tests may); the GPU test uses the product
 path and compares trajectories with the oracle-driven loop."""
+import os
+
 import numpy as np
 import pytest
 
@@ -286,3 +288,39 @@ def test_sample_trajectory_capture(hip_lib, extended):
     np.testing.assert_allclose(dev["x_traj"][0], 0.0, atol=0)
     again = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended)          # the setting is per call
     assert "x_traj" not in again
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", ["wave", "block"])
+def test_per_solve_device_times(hip_lib, path):
+    """tmpc_set_solve_timing: the computational times the reference's controllers keep per solve (TubeTrackingMPC.py:205,
+    242-243) and its scripts summarise (results_linear_system.py:305-315), taken per instance on the device.  Timing must not
+    change any result; an instance that takes interior-point iterations takes longer than one the unconstrained minimiser
+    solves; a trajectory's maximum is at least its mean."""
+    S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))[:256]
+    mpc, w = common.make_mpc("cartpole", 10, True, create=True)
+    mpc.set_kernel_path(path)
+    X = np.r_[S[:, :4], np.zeros((8, 4))]                       # eight instances at the origin tracking 0: no active row
+    R = np.r_[S[:, 4:], np.zeros((8, 4))]
+    plain = mpc._solve(X, R)
+    timed = mpc._solve(X, R, timing=True)
+    for key in ("u_nom", "x_nom0", "status", "iters"):
+        np.testing.assert_array_equal(timed[key], plain[key], err_msg=key)
+    t = timed["solve_time"]
+    assert t.shape == (len(X),) and np.all(t > 0) and np.all(t < 1.0)
+    assert np.all(timed["iters"][-8:] == 0)
+    assert np.median(t[:-8][timed["iters"][:-8] > 0]) > 2 * np.median(t[-8:])
+    assert "solve_time" not in mpc._solve(X, R)                  # the setting is per call
+    if path == "wave":
+        nb, T = 32, 40
+        p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+        th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=5)
+        ref = np.full(T, 0.4)
+        a = mpc.run_closed_loop(p_loss, ref, th, ga, dist)
+        b = mpc.run_closed_loop(p_loss, ref, th, ga, dist, timing=True)
+        for key in ("err2", "tube_violations", "not_optimal", "x_final", "iters_sum"):
+            np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+        assert np.all(b["solve_time_mean"] > 0) and np.all(b["solve_time_max"] >= b["solve_time_mean"])
+        assert len(mpc.get_computational_times()) >= nb
+        table, _ = montecarlo.mc_sweep(mpc, w, np.array([0.0, 0.5]), 4, 30, 0.3, on_device=True, timing=True)
+        assert table.shape == (8, 5) and np.all(table[:, 3] > 0) and np.all(table[:, 4] >= table[:, 3])
