@@ -254,6 +254,12 @@ int tmpc_mc_get_capture(tmpc_handle *h, int32_t T, double *x_traj, double *x_nom
 #define TMPC_PLANT_LINEAR   0
 #define TMPC_PLANT_CARTPOLE 1
 int tmpc_mc_set_plant(tmpc_handle *h, int kind, const double *par7, int substeps);
+/*
+ * With a nonlinear plant tmpc_mc_run also sums |x - ref|^2 over the T * substeps physics steps (the state at the start of
+ * every physics step, i.e. x_traj[:, 0:-1] of results_nonlinear_system.py:361, whose tracking error is taken at 500 Hz);
+ * copied out per trajectory by tmpc_mc_get_physics_error (NaN for an R-MPC trajectory that stopped).
+ */
+int tmpc_mc_get_physics_error(tmpc_handle *h, int64_t B, double *err2_phys);
 
 /*
  * Plant-side actuator simulated by tmpc_mc_run.  TMPC_ACTUATOR_CONSISTENT (default): ConsistentActuator with nominal

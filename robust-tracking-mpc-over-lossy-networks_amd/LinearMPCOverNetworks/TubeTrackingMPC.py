@@ -228,7 +228,8 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         _native.mc_set_plant(self._handle, plant)        # None: the linear model; 'cartpole': the nonlinear cart-pole (RK4, 500 Hz)
         _native.mc_set_actuator(self._handle, self._smart_actuator)
         out = _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
-                             extended=extended, warm_start=warm_start, capture=capture, timing=timing)
+                             extended=extended, warm_start=warm_start, capture=capture, timing=timing,
+                             physics_substeps=0 if plant in (None, "linear") else 10)
         if timing:
             self._computational_times.extend(out["solve_time_mean"].tolist())
         return out

@@ -98,6 +98,8 @@ def lib():
         L.tmpc_get_solve_ticks.restype = C.c_int
         L.tmpc_mc_get_solve_ticks.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.tmpc_mc_get_solve_ticks.restype = C.c_int
+        L.tmpc_mc_get_physics_error.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.tmpc_mc_get_physics_error.restype = C.c_int
         L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_warm_start.restype = C.c_int
         L.tmpc_mc_run.restype = C.c_int
@@ -310,11 +312,13 @@ def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
 
 
 def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False,
-           capture=None, timing: bool = False) -> dict:
+           capture=None, timing: bool = False, physics_substeps: int = 0) -> dict:
     """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device.
     warm_start: tmpc_mc_set_warm_start for this call; capture: index of a trajectory to record (tmpc_mc_set_capture) ->
     x_traj (T, nx), x_nom_traj (T, nx), u_traj (T, nu) in the result; timing: per trajectory the mean and the maximum
-    time of its T solves in seconds (solve_time_mean, solve_time_max; tmpc_set_solve_timing)."""
+    time of its T solves in seconds (solve_time_mean, solve_time_max; tmpc_set_solve_timing); physics_substeps > 0 (a
+    nonlinear plant was set with that many steps per sampling period): tracking_error_physics, the scripts' tracking error
+    over the physics-rate trajectory (tmpc_mc_get_physics_error, results_nonlinear_system.py:361)."""
     if lib().tmpc_set_solve_timing(h.ptr, int(bool(timing))) != 0:
         raise RuntimeError(h.error())
     if lib().tmpc_mc_set_warm_start(h.ptr, int(bool(warm_start))) != 0:
@@ -349,6 +353,11 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
         if lib().tmpc_mc_get_solve_ticks(h.ptr, B, tsum.ctypes.data, tmax.ctypes.data) != 0:
             raise RuntimeError(h.error())
         out["solve_time_mean"], out["solve_time_max"] = tsum * (TICK_SECONDS / max(T, 1)), tmax * TICK_SECONDS
+    if physics_substeps > 0:
+        out["err2_physics"] = np.empty(B)
+        if lib().tmpc_mc_get_physics_error(h.ptr, B, ptr(out["err2_physics"])) != 0:
+            raise RuntimeError(h.error())
+        out["tracking_error_physics"] = np.sqrt(out["err2_physics"]) / (T * physics_substeps)
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
     out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve

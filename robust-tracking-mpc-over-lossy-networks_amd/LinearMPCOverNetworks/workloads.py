@@ -83,18 +83,26 @@ def cartpole_rhs(x, F, par=CARTPOLE_PARAMS):
     return np.stack([vel, acc, om, alp], axis=-1)
 
 
-def cartpole_step(x, F, Th: float = 0.02, substeps: int = 10, par=CARTPOLE_PARAMS):
+def cartpole_trace(x, F, Th: float = 0.02, substeps: int = 10, par=CARTPOLE_PARAMS):
     """Zero-order hold of the force over one sampling period Th, classical RK4 with `substeps` steps (500 Hz for
-    Th = 20 ms, the reference's physics rate, results_nonlinear_system.py:30-37)."""
+    Th = 20 ms, the reference's physics rate, results_nonlinear_system.py:30-37).  Returns the states at the physics
+    steps, (substeps + 1, ...): [0] = x, [-1] = the state one sampling period later."""
     x = np.array(x, dtype=np.float64)
     dt = Th / substeps
+    xs = [x]
     for _ in range(substeps):
         k1 = cartpole_rhs(x, F, par)
         k2 = cartpole_rhs(x + 0.5 * dt * k1, F, par)
         k3 = cartpole_rhs(x + 0.5 * dt * k2, F, par)
         k4 = cartpole_rhs(x + dt * k3, F, par)
         x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
-    return x
+        xs.append(x)
+    return np.stack(xs)
+
+
+def cartpole_step(x, F, Th: float = 0.02, substeps: int = 10, par=CARTPOLE_PARAMS):
+    """The state one sampling period later (cartpole_trace)."""
+    return cartpole_trace(x, F, Th, substeps, par)[-1]
 
 
 # --------------------------------------------------------------------------- controllers for the named workloads

@@ -70,6 +70,8 @@ struct tmpc_handle {
     int64_t ticks_cap = 0, ticks_n = 0;
     long long *d_ticks = nullptr;
     long long *mc_tick_sum = nullptr, *mc_tick_max = nullptr;      // inside mc_arena, of the last tmpc_mc_run
+    double *mc_err2_phys = nullptr;                                 // likewise (nonlinear plant only)
+    int64_t mc_phys_B = 0;
     int64_t mc_tick_B = 0;
     std::string err;
 };
@@ -673,6 +675,15 @@ int tmpc_mc_get_solve_ticks(tmpc_handle *h, int64_t B, int64_t *ticks_sum, int64
     return TMPC_OK;
 }
 
+int tmpc_mc_get_physics_error(tmpc_handle *h, int64_t B, double *err2_phys) {
+    if (!h || !err2_phys) return TMPC_E_INVALID;
+    if (!h->mc_err2_phys || B != h->mc_phys_B) { h->err = "tmpc_mc_get_physics_error: the last tmpc_mc_run had the linear plant or another batch size"; return TMPC_E_INVALID; }
+    HIP_TRY(h, hipSetDevice(h->device));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(err2_phys, h->mc_err2_phys, static_cast<size_t>(B) * sizeof(double), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
 int tmpc_mc_set_warm_start(tmpc_handle *h, int on) {
     if (!h) return TMPC_E_INVALID;
     h->mc_warm = on ? 1 : 0;
@@ -696,7 +707,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
     const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + 2 * t_ + t_ * nx)) +
-                        8 * b * (6 * nx + (N + 1) * nu + nu + 4) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
+                        8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
     if (need > h->mc_arena_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mc_arena) (void)hipFree(h->mc_arena);
@@ -768,6 +779,13 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             st.cap_index = h->mc_capture;
             h->mc_cap_dev = st.cap;
             h->mc_cap_T = T;
+        }
+        h->mc_err2_phys = nullptr;
+        h->mc_phys_B = 0;
+        if (m.plant != TMPC_PLANT_LINEAR) {
+            if ((r2 = dalloc(b * 8, reinterpret_cast<void **>(&st.err2_phys)))) return r2;
+            HIP_TRY(h, hipMemsetAsync(st.err2_phys, 0, b * 8, h->stream));
+            h->mc_err2_phys = st.err2_phys; h->mc_phys_B = B;
         }
         h->mc_tick_sum = h->mc_tick_max = nullptr;
         h->mc_tick_B = 0;

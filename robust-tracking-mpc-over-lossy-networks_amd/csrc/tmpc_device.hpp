@@ -112,6 +112,7 @@ struct McState {                         // all [trajectory]-major device arrays
     double *ref_k;                       // reference handed to the solve                                       [B][nx]
     double *e_buf;                       // x_t - x_nom_t of the current step, for the tube membership kernel    [B][nx]
     double *err2, *consistent;           // statistics                                                          [B]
+    double *err2_phys;                   // sum of |x - ref|^2 over the physics steps of a nonlinear plant (or nullptr)  [B]
     int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal, *iters_sum;
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
     uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]

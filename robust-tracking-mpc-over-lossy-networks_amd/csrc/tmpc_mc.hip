@@ -70,6 +70,7 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     if (m.smart && bad) {          // R-MPC branch: the trajectory ends here (:268-270), its tracking error is NaN (:297)
         st.dead[b] = 1;
         st.err2[b] = __longlong_as_double(0x7ff8000000000000ll);
+        if (st.err2_phys) st.err2_phys[b] = __longlong_as_double(0x7ff8000000000000ll);
         return;
     }
 
@@ -142,8 +143,10 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
         // zero-order hold of u over the sampling period, RK4 at the physics rate; the nominal model stays linear
         double y[4] = {x[0], x[1], x[2], x[3]};
         const double dt = m.par[6] / m.substeps;
+        double aphys = 0.0;       // tracking error at the physics rate (results_nonlinear_system.py:361: x_traj[:, 0:-1], 500 Hz)
         for (int sstep = 0; sstep < m.substeps; ++sstep) {
             double k1[4], k2[4], k3[4], k4[4], yt[4];
+            aphys += (y[0] - ref_t) * (y[0] - ref_t) + y[1] * y[1] + y[2] * y[2] + y[3] * y[3];
             cartpole_rhs(m.par, y, u[0], k1);
             for (int i = 0; i < 4; ++i) yt[i] = y[i] + 0.5 * dt * k1[i];
             cartpole_rhs(m.par, yt, u[0], k2);
@@ -154,6 +157,7 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
             for (int i = 0; i < 4; ++i) y[i] += dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
         }
         for (int i = 0; i < 4; ++i) xp[i] = y[i] + st.w[(b * T + t) * nx + i];
+        if (st.err2_phys) st.err2_phys[b] += aphys;
     }
     for (int i = 0; i < nx; ++i) { st.x[b * nx + i] = xp[i]; st.x_nom[b * nx + i] = xnp[i]; }
     // ---- estimator (Estimator.py:43-98; robust: :113-156)

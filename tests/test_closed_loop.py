@@ -139,6 +139,10 @@ def test_device_loop_with_nonlinear_plant_equals_host_loop(hip_lib):
     assert np.all(dev["not_optimal"] == 0)
     np.testing.assert_allclose(dev["x_final"], host["x_final"], atol=1e-8, rtol=0)
     np.testing.assert_allclose(dev["tracking_error"], host["tracking_error"], atol=1e-10, rtol=0)
+    # tracking error over the physics-rate trajectory (results_nonlinear_system.py:361: x_traj[:, 0:-1] at 500 Hz)
+    np.testing.assert_allclose(dev["tracking_error_physics"], host["tracking_error_physics"], atol=1e-10, rtol=0)
+    assert "tracking_error_physics" not in lin
+    assert np.all(np.abs(dev["tracking_error_physics"] * np.sqrt(10.0) - dev["tracking_error"]) < 0.2 * dev["tracking_error"])
     assert np.array_equal(dev["tube_violations"], host["tube_violations"])
     # the nonlinear plant really is a different plant, and the loop still tracks the reference
     assert np.max(np.abs(dev["x_final"] - lin["x_final"])) > 1e-6
