@@ -245,6 +245,19 @@ int tmpc_mc_set_capture(tmpc_handle *h, int64_t index);
 int tmpc_mc_get_capture(tmpc_handle *h, int32_t T, double *x_traj, double *x_nom_traj, double *u_traj);
 
 /*
+ * Realisations drawn on the device (throughput runs: the host arrays of a 10 x 1000 x 250 sweep are 120 MB and their
+ * generation takes longer than the closed loop).  With tmpc_mc_set_device_rng(on = 1, seed, first_trajectory, w_bound)
+ * the following tmpc_mc_run calls ignore th_u, ga_u and w (NULL allowed) and draw, for trajectory b of the call and step t,
+ * from Philox4x64-10 with key (seed, first_trajectory + b) and counter (t, j, 0, 0): block j = 0 gives the theta and gamma
+ * uniforms and w_0, w_1, block j >= 1 gives w_{4j-2} .. w_{4j+1}; a uniform is (x >> 11) * 2^-53, a disturbance component
+ * w_bound[i] * (2 u - 1) (the reference draws rng_w.uniform(-w_bound, w_bound), results_linear_system.py:229-233).
+ * A trajectory's stream depends on (seed, its global index, t) only -- not on the batch it is solved in nor on the rank.
+ * LinearMPCOverNetworks.montecarlo.draw_realisations_philox is the numpy twin (tests: identical closed loops).
+ * w_bound: nx half-widths, NULL = no disturbance.  on = 0 returns to host arrays.
+ */
+int tmpc_mc_set_device_rng(tmpc_handle *h, int on, uint64_t seed, int64_t first_trajectory, const double *w_bound);
+
+/*
  * Plant simulated by tmpc_mc_run.  TMPC_PLANT_LINEAR (default): x+ = A x + B u + w (results_linear_system.py:248).
  * TMPC_PLANT_CARTPOLE: the nonlinear cart-pole the linear model was derived from (results_linear_system.py:26-47;
  * the reference integrates it with PyBullet at 500 Hz, results_nonlinear_system.py:30-37), zero-order hold of the

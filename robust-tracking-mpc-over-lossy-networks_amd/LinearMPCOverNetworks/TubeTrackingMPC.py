@@ -213,15 +213,17 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         U = np.concatenate([out["u_nom"], u_ss[:, None, :]], axis=1)     # (B, N+1, nu)
         return np.ascontiguousarray(U.transpose(0, 2, 1)), out["x_nom0"], out["status"]
 
-    def run_closed_loop(self, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False, plant=None, warm_start: bool = False,
-                        capture=None, timing: bool = False) -> dict:
+    def run_closed_loop(self, p_loss, ref, th_u=None, ga_u=None, w=None, x0=None, extended: bool = False, plant=None,
+                        warm_start: bool = False, capture=None, timing: bool = False, device_rng=None) -> dict:
         """The lossy-network closed loop of the reference's Monte-Carlo scripts (results_linear_system.py:209-291)
         for a batch of trajectories, resident on the device (include/tmpc.h: tmpc_mc_run): every time step is one
         solve launch plus one state-machine launch, nothing returns to the host in between.  warm_start: every solve first
         tries the working set of the trajectory's previous solve in the exact refinement (same results, fewer iterations);
         capture: index of one trajectory whose x_t / x_nom_t / u_t are returned (the scripts' sample run, :298-301).
         timing: per trajectory the mean / maximum device time of a solve (solve_time_mean, solve_time_max, seconds); the
-        means are also appended to get_computational_times(), the list the scripts take their quantiles of (:305-315)."""
+        means are also appended to get_computational_times(), the list the scripts take their quantiles of (:305-315).
+        device_rng = (seed, first_trajectory, w_bound): draw the realisations on the device instead of taking th_u, ga_u, w
+        (tmpc_mc_set_device_rng; montecarlo.draw_realisations_philox is the host twin)."""
         from . import _native
         if self._handle is None:
             raise RuntimeError("setup_optimization() has not been called")
@@ -229,7 +231,7 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         _native.mc_set_actuator(self._handle, self._smart_actuator)
         out = _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
                              extended=extended, warm_start=warm_start, capture=capture, timing=timing,
-                             physics_substeps=0 if plant in (None, "linear") else 10)
+                             physics_substeps=0 if plant in (None, "linear") else 10, device_rng=device_rng)
         if timing:
             self._computational_times.extend(out["solve_time_mean"].tolist())
         return out

@@ -98,6 +98,8 @@ def lib():
         L.tmpc_get_solve_ticks.restype = C.c_int
         L.tmpc_mc_get_solve_ticks.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.tmpc_mc_get_solve_ticks.restype = C.c_int
+        L.tmpc_mc_set_device_rng.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_int64, C.c_void_p]
+        L.tmpc_mc_set_device_rng.restype = C.c_int
         L.tmpc_mc_get_physics_error.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
         L.tmpc_mc_get_physics_error.restype = C.c_int
         L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
@@ -312,13 +314,16 @@ def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
 
 
 def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False,
-           capture=None, timing: bool = False, physics_substeps: int = 0) -> dict:
+           capture=None, timing: bool = False, physics_substeps: int = 0, device_rng=None) -> dict:
     """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device.
     warm_start: tmpc_mc_set_warm_start for this call; capture: index of a trajectory to record (tmpc_mc_set_capture) ->
     x_traj (T, nx), x_nom_traj (T, nx), u_traj (T, nu) in the result; timing: per trajectory the mean and the maximum
     time of its T solves in seconds (solve_time_mean, solve_time_max; tmpc_set_solve_timing); physics_substeps > 0 (a
     nonlinear plant was set with that many steps per sampling period): tracking_error_physics, the scripts' tracking error
-    over the physics-rate trajectory (tmpc_mc_get_physics_error, results_nonlinear_system.py:361)."""
+    over the physics-rate trajectory (tmpc_mc_get_physics_error, results_nonlinear_system.py:361).
+    device_rng = (seed, first_trajectory, w_bound): the realisations are drawn on the device (tmpc_mc_set_device_rng;
+    montecarlo.draw_realisations_philox gives the same numbers on the host); th_u, ga_u, w are then ignored and may be None,
+    the batch is len(p_loss) x len(ref)."""
     if lib().tmpc_set_solve_timing(h.ptr, int(bool(timing))) != 0:
         raise RuntimeError(h.error())
     if lib().tmpc_mc_set_warm_start(h.ptr, int(bool(warm_start))) != 0:
@@ -326,10 +331,21 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
     if lib().tmpc_mc_set_capture(h.ptr, -1 if capture is None else int(capture)) != 0:
         raise RuntimeError(h.error())
     c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
-    th_u, ga_u, w, p_loss, ref = c(th_u), c(ga_u), c(w), c(p_loss), c(ref)
-    B, T = th_u.shape
-    if ga_u.shape != (B, T) or w.shape != (B, T, h.nx) or p_loss.shape != (B,) or ref.shape != (T,):
-        raise ValueError("mc_run: inconsistent shapes")
+    p_loss, ref = c(p_loss), c(ref)
+    if device_rng is not None:
+        seed, first, w_bound = device_rng
+        wb = None if w_bound is None else c(w_bound).reshape(h.nx)
+        if lib().tmpc_mc_set_device_rng(h.ptr, 1, int(seed), int(first), None if wb is None else wb.ctypes.data) != 0:
+            raise RuntimeError(h.error())
+        th_u = ga_u = w = None
+        B, T = p_loss.shape[0], ref.shape[0]
+    else:
+        if lib().tmpc_mc_set_device_rng(h.ptr, 0, 0, 0, None) != 0:
+            raise RuntimeError(h.error())
+        th_u, ga_u, w = c(th_u), c(ga_u), c(w)
+        B, T = th_u.shape
+        if ga_u.shape != (B, T) or w.shape != (B, T, h.nx) or p_loss.shape != (B,) or ref.shape != (T,):
+            raise ValueError("mc_run: inconsistent shapes")
     x0c = None if x0 is None else c(x0).reshape(B, h.nx)
     HZ = hZ = None
     rZ = 0

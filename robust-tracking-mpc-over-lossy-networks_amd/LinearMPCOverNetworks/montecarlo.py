@@ -67,6 +67,56 @@ def draw_realisations(n_traj: int, T: int, w_bound, seed: int = 20240301, first:
     return th, ga, w
 
 
+# Philox4x64-10 (Salmon et al., SC'11), the numpy twin of the device generator in csrc/tmpc_mc.hip (tmpc_mc_set_device_rng).
+_PHILOX_M0, _PHILOX_M1 = 0xD2E7470EE14C6C93, 0xCA5A826395121157
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B97F4A7C15, 0xBB67AE8584CAA73B
+
+
+def _mulhilo64(a, b: int):
+    """(high, low) 64-bit halves of a * b for a uint64 array a and a 64-bit constant b."""
+    m32 = np.uint64(0xFFFFFFFF)
+    s32 = np.uint64(32)
+    a0, a1 = a & m32, a >> s32
+    b0, b1 = np.uint64(b & 0xFFFFFFFF), np.uint64(b >> 32)
+    p00, p01, p10, p11 = a0 * b0, a0 * b1, a1 * b0, a1 * b1
+    carry = ((p00 >> s32) + (p01 & m32) + (p10 & m32)) >> s32
+    return p11 + (p01 >> s32) + (p10 >> s32) + carry, a * np.uint64(b)
+
+
+def philox4x64(c0, c1, k0, k1):
+    """Ten rounds of Philox-4x64 on the counter (c0, c1, 0, 0) with the key (k0, k1), vectorised: arrays that broadcast
+    against each other -> (4, ...) uint64.  numpy.random.Philox(key=[k0, k1], counter=[c0 - 1, c1, 0, 0]).random_raw(4) gives
+    the same four words (numpy increments the counter before it generates; tests/test_condense.py pins this)."""
+    with np.errstate(over="ignore"):
+        c0, c1, k0, k1 = np.broadcast_arrays(*(np.asarray(v, dtype=np.uint64) for v in (c0, c1, k0, k1)))
+        c = [c0.copy(), c1.copy(), np.zeros_like(c0), np.zeros_like(c0)]
+        k0, k1 = k0.copy(), k1.copy()
+        for _ in range(10):
+            hi0, lo0 = _mulhilo64(c[0], _PHILOX_M0)
+            hi1, lo1 = _mulhilo64(c[2], _PHILOX_M1)
+            c = [hi1 ^ c[1] ^ k0, lo1, hi0 ^ c[3] ^ k1, lo0]
+            k0 = k0 + np.uint64(_PHILOX_W0)
+            k1 = k1 + np.uint64(_PHILOX_W1)
+    return np.stack(c)
+
+
+def draw_realisations_philox(n_traj: int, T: int, w_bound, seed: int = 20240301, first: int = 0):
+    """The realisations tmpc_mc_run draws on the device with tmpc_mc_set_device_rng(seed, first, w_bound), reproduced on the
+    host (include/tmpc.h): trajectory g = first + i, step t: Philox4x64-10 with key (seed, g), counter (t, j, 0, 0);
+    block 0 = [theta, gamma, w_0, w_1], block j = w_{4j-2} .. w_{4j+1}; u = (x >> 11) 2^-53; w_i = w_bound_i (2 u - 1).
+    Like draw_realisations, a trajectory's stream does not depend on how the sweep is sharded."""
+    w_bound = np.asarray(w_bound, dtype=np.float64).reshape(-1)
+    nx = w_bound.size
+    g = (np.uint64(first) + np.arange(n_traj, dtype=np.uint64))[:, None]
+    t = np.arange(T, dtype=np.uint64)[None, :]
+    nblk = (nx + 2 + 3) // 4
+    words = np.concatenate([philox4x64(t, np.uint64(j), np.uint64(seed), g) for j in range(nblk)], axis=0)     # (4 nblk, n, T)
+    u = (words >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    th, ga = u[0], u[1]
+    w = np.moveaxis(u[2:2 + nx], 0, -1) * 2.0 - 1.0
+    return np.ascontiguousarray(th), np.ascontiguousarray(ga), np.ascontiguousarray(w * w_bound)
+
+
 def draw_realisations_reference_order(p_loss, n_mc: int, T: int, w_bound, seeds=(679, 347, 124)):
     """The realisations of the reference's own experiment: three shared generators -- disturbance 679, gamma 347,
     theta 124 (results_linear_system.py:21-23) -- consumed in loop order over (loss rate i, run l_mc, step t): one theta
@@ -243,23 +293,30 @@ def plant_callable(plant):
 
 def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
              extended: bool = False, device=None, on_device: bool = False, plant=None, warm_start: bool = False,
-             timing: bool = False):
+             timing: bool = False, device_rng: bool = False):
     """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
     trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
     shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
     Returns (table (n_total, 3) = [tracking error, tube violations, non-optimal solves], p_index (n_total,)),
     identical on every rank.  timing (device loop only): two more columns, the mean and the maximum device time of a
-    trajectory's solves in seconds -- the computational times results_linear_system.py:305-315 reports."""
+    trajectory's solves in seconds -- the computational times results_linear_system.py:305-315 reports.
+    device_rng: Philox streams keyed by (seed, global trajectory index), drawn on the device in the device loop
+    (tmpc_mc_set_device_rng) and by draw_realisations_philox, the same numbers, in the host loops."""
     import torch
     p_loss = np.asarray(p_loss, dtype=np.float64)
     pi, _ = trajectory_table(p_loss, n_mc)
     n_total = len(pi)
     lo, hi = shard_bounds(n_total, rank, world)
-    th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
+    if device_rng and on_device:
+        th = ga = w = None
+    elif device_rng:
+        th, ga, w = draw_realisations_philox(hi - lo, T, model["w_bound"], seed=seed, first=lo)
+    else:
+        th, ga, w = draw_realisations(hi - lo, T, model["w_bound"], seed=seed, first=lo)
     ref = np.broadcast_to(np.asarray(ref, dtype=np.float64), (T,))
     if on_device:        # state machines on the GPU as well (tmpc_mc_run); otherwise the host loop around determine_packets
         out = mpc.run_closed_loop(p_loss[pi[lo:hi]], ref, th, ga, w, extended=extended, plant=plant, warm_start=warm_start,
-                                  timing=timing)
+                                  timing=timing, device_rng=(seed, lo, model["w_bound"]) if device_rng else None)
     elif getattr(mpc, "_smart_actuator", False):       # TrackingMPC: the comparator's loop (results_linear_system.py:262-287)
         out = run_remote_tracking_mpc(mpc.determine_packets, model["A"], model["B"], mpc.get_steady_state_controller_gain(), mpc._N,
                                       p_loss[pi[lo:hi]], ref, th, ga, w)

@@ -71,6 +71,10 @@ struct tmpc_handle {
     long long *d_ticks = nullptr;
     long long *mc_tick_sum = nullptr, *mc_tick_max = nullptr;      // inside mc_arena, of the last tmpc_mc_run
     double *mc_err2_phys = nullptr;                                 // likewise (nonlinear plant only)
+    int mc_rng_on = 0;                                              // tmpc_mc_set_device_rng
+    uint64_t mc_rng_seed = 0;
+    int64_t mc_rng_first = 0;
+    std::vector<double> mc_w_bound;
     int64_t mc_phys_B = 0;
     int64_t mc_tick_B = 0;
     std::string err;
@@ -675,6 +679,17 @@ int tmpc_mc_get_solve_ticks(tmpc_handle *h, int64_t B, int64_t *ticks_sum, int64
     return TMPC_OK;
 }
 
+int tmpc_mc_set_device_rng(tmpc_handle *h, int on, uint64_t seed, int64_t first_trajectory, const double *w_bound) {
+    if (!h) return TMPC_E_INVALID;
+    h->mc_rng_on = on ? 1 : 0;
+    h->mc_rng_seed = seed;
+    h->mc_rng_first = first_trajectory;
+    h->mc_w_bound.assign(static_cast<size_t>(h->nx), 0.0);
+    if (on && w_bound)
+        for (int i = 0; i < h->nx; ++i) h->mc_w_bound[i] = w_bound[i];
+    return TMPC_OK;
+}
+
 int tmpc_mc_get_physics_error(tmpc_handle *h, int64_t B, double *err2_phys) {
     if (!h || !err2_phys) return TMPC_E_INVALID;
     if (!h->mc_err2_phys || B != h->mc_phys_B) { h->err = "tmpc_mc_get_physics_error: the last tmpc_mc_run had the linear plant or another batch size"; return TMPC_E_INVALID; }
@@ -695,7 +710,8 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
                 int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent,
                 int32_t *iters_sum) {
     if (!h) return TMPC_E_INVALID;
-    if (B < 0 || T < 0 || !p_loss || !ref || !th_u || !ga_u || !w || (rZ > 0 && (!HZ || !hZ))) { h->err = "tmpc_mc_run: NULL argument"; return TMPC_E_INVALID; }
+    const bool host_draws = !h->mc_rng_on;
+    if (B < 0 || T < 0 || !p_loss || !ref || (host_draws && (!th_u || !ga_u || !w)) || (rZ > 0 && (!HZ || !hZ))) { h->err = "tmpc_mc_run: NULL argument"; return TMPC_E_INVALID; }
     if (h->device < 0) { h->err = "host-only handle (device < 0): nothing can be solved without the GPU"; return TMPC_E_DEVICE; }
     if (extended && h->nvariants < 2) { h->err = "tmpc_mc_run: extended loop needs a problem created with extended = 1"; return TMPC_E_INVALID; }
     if (h->hK.empty() || h->hKanc.empty()) { h->err = "tmpc_mc_run: the problem description carries no gains K / K_anc"; return TMPC_E_INVALID; }
@@ -706,7 +722,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     if (rc) return rc;
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
-    const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + 2 * t_ + t_ * nx)) +
+    const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
                         8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
     if (need > h->mc_arena_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -746,9 +762,16 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
         if ((r2 = up(HZ, static_cast<size_t>(rZ) * nx * 8, reinterpret_cast<const void **>(&m.HZ)))) return r2;
         if ((r2 = up(hZ, static_cast<size_t>(rZ) * 8, reinterpret_cast<const void **>(&m.hZ)))) return r2;
         if ((r2 = up(p_loss, b * 8, reinterpret_cast<const void **>(&st.p_loss)))) return r2;
-        if ((r2 = up(th_u, b * t_ * 8, reinterpret_cast<const void **>(&st.th_u)))) return r2;
-        if ((r2 = up(ga_u, b * t_ * 8, reinterpret_cast<const void **>(&st.ga_u)))) return r2;
-        if ((r2 = up(w, b * t_ * nx * 8, reinterpret_cast<const void **>(&st.w)))) return r2;
+        if (host_draws) {
+            if ((r2 = up(th_u, b * t_ * 8, reinterpret_cast<const void **>(&st.th_u)))) return r2;
+            if ((r2 = up(ga_u, b * t_ * 8, reinterpret_cast<const void **>(&st.ga_u)))) return r2;
+            if ((r2 = up(w, b * t_ * nx * 8, reinterpret_cast<const void **>(&st.w)))) return r2;
+        } else {
+            st.rng_on = 1;
+            st.rng_seed = h->mc_rng_seed;
+            st.rng_first = h->mc_rng_first;
+            if ((r2 = up(h->mc_w_bound.data(), nx * 8, reinterpret_cast<const void **>(&st.w_bound)))) return r2;
+        }
         struct { void **p; size_t bytes; int fill; } arrays[] = {
             {reinterpret_cast<void **>(&st.x), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.x_hat), b * nx * 8, 0},
             {reinterpret_cast<void **>(&st.x_nom), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.Ubuf), b * (N + 1) * nu * 8, 0},

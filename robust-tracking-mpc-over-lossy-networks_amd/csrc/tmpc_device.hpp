@@ -117,6 +117,12 @@ struct McState {                         // all [trajectory]-major device arrays
     uint8_t *gamma;                      // arrival of the previous plant packet = variant of the next solve   [B]
     uint8_t *dead;                       // trajectory stopped after an infeasible solve (smart actuator only)      [B]
     const double *p_loss, *th_u, *ga_u, *w;   // realisations: [B], [B][T], [B][T], [B][T][nx]
+    // realisations drawn on the device instead (tmpc_mc_set_device_rng; th_u, ga_u, w are then not read): Philox4x64-10,
+    // key = (seed, first trajectory + b), counter = (t, block, 0, 0); block 0 = [theta, gamma, w_0, w_1], block j = w_{4j-2 ..}
+    int rng_on;
+    unsigned long long rng_seed;
+    long long rng_first;
+    const double *w_bound;                    // [nx] half-widths of the disturbance box
     const long long *ticks;                   // per-solve durations of the step just solved, or nullptr                [B]
     long long *tick_sum, *tick_max;           // their sum and maximum along the trajectory (with ticks)                 [B]
     long long cap_index;                      // trajectory whose states are recorded (-1: none)

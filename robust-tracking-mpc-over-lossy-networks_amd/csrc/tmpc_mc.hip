@@ -41,6 +41,43 @@ __device__ __forceinline__ void cartpole_rhs(const double *par, const double (&x
     dx[3] = (a11 * r2 - a12 * r1) / det;
 }
 
+// Philox4x64-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11; the generator behind
+// numpy.random.Philox, against which montecarlo.philox4x64 -- the numpy twin of this function -- is pinned in the tests).
+__device__ __forceinline__ void philox4x64(unsigned long long c0, unsigned long long c1, unsigned long long k0, unsigned long long k1,
+                                           unsigned long long (&out)[4]) {
+    unsigned long long c[4] = {c0, c1, 0ull, 0ull};
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long m0 = 0xD2E7470EE14C6C93ull, m1 = 0xCA5A826395121157ull;
+        const unsigned long long hi0 = __umul64hi(m0, c[0]), lo0 = m0 * c[0];
+        const unsigned long long hi1 = __umul64hi(m1, c[2]), lo1 = m1 * c[2];
+        c[0] = hi1 ^ c[1] ^ k0; c[1] = lo1; c[2] = hi0 ^ c[3] ^ k1; c[3] = lo0;
+        k0 += 0x9E3779B97F4A7C15ull; k1 += 0xBB67AE8584CAA73Bull;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+__device__ __forceinline__ double u01(unsigned long long x) { return static_cast<double>(x >> 11) * 0x1.0p-53; }   // [0, 1), 53 bits
+// the step's draws of trajectory b: theta and gamma uniforms, disturbance w (nx <= 16)
+__device__ __forceinline__ void mc_draws(const McState &st, int64_t b, int t, int T, int nx, double &th, double &ga, double *w) {
+    if (!st.rng_on) {
+        th = st.th_u[b * T + t];
+        ga = st.ga_u[b * T + t];
+        for (int i = 0; i < nx; ++i) w[i] = st.w[(b * T + t) * nx + i];
+        return;
+    }
+    const unsigned long long key1 = static_cast<unsigned long long>(st.rng_first + b);
+    unsigned long long r[4];
+    philox4x64(static_cast<unsigned long long>(t), 0ull, st.rng_seed, key1, r);
+    th = u01(r[0]);
+    ga = u01(r[1]);
+    for (int i = 0; i < nx; ++i) {
+        const int idx = i + 2;
+        if (idx >= 4 && (idx & 3) == 0) philox4x64(static_cast<unsigned long long>(t), static_cast<unsigned long long>(idx >> 2), st.rng_seed, key1, r);
+        w[i] = st.w_bound[i] * (2.0 * u01(r[idx & 3]) - 1.0);
+    }
+}
+
 __global__ void mc_pre_kernel(const McModel m, const McState st, const int t, const int64_t B, const double ref_t) {
     const int64_t b = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -56,7 +93,9 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     const int nx = m.nx, nu = m.nu, N = m.N;
     if (st.dead[b]) return;                                                              // results_linear_system.py:262
     const double p = st.p_loss[b];
-    int theta = (t > 0 && st.th_u[b * T + t] < p) ? 0 : 1;                               // strict <, first packet always arrives
+    double th_draw, ga_draw, w_draw[MAXN];
+    mc_draws(st, b, t, T, nx, th_draw, ga_draw, w_draw);
+    int theta = (t > 0 && th_draw < p) ? 0 : 1;                                          // strict <, first packet always arrives
     const int stat = status[b];
     const bool bad = stat >= 2;
     if (stat != 0) st.not_optimal[b] += 1;
@@ -133,7 +172,7 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
     // ---- plant and nominal model
     double xp[MAXN], xnp[MAXN];
     for (int i = 0; i < nx; ++i) {
-        double v = st.w[(b * T + t) * nx + i], vn = 0.0;
+        double v = w_draw[i], vn = 0.0;
         for (int k = 0; k < nx; ++k) { v += m.A[i * nx + k] * x[k]; vn += m.A[i * nx + k] * xn[k]; }
         for (int j = 0; j < nu; ++j) { v += m.B[i * nu + j] * u[j]; vn += m.B[i * nu + j] * un[j]; }
         xp[i] = v;
@@ -156,12 +195,12 @@ __global__ void mc_post_kernel(const McModel m, const McState st, const int t, c
             cartpole_rhs(m.par, yt, u[0], k4);
             for (int i = 0; i < 4; ++i) y[i] += dt / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
         }
-        for (int i = 0; i < 4; ++i) xp[i] = y[i] + st.w[(b * T + t) * nx + i];
+        for (int i = 0; i < 4; ++i) xp[i] = y[i] + w_draw[i];
         if (st.err2_phys) st.err2_phys[b] += aphys;
     }
     for (int i = 0; i < nx; ++i) { st.x[b * nx + i] = xp[i]; st.x_nom[b * nx + i] = xnp[i]; }
     // ---- estimator (Estimator.py:43-98; robust: :113-156)
-    const int gamma = (t > 0 && st.ga_u[b * T + t] < p) ? 0 : 1;
+    const int gamma = (t > 0 && ga_draw < p) ? 0 : 1;
     double xh[MAXN];
     if (gamma) {
         // packet {'x_t', 's_t'[, 'x_nom_t']}: x_t = nominal state (consistent actuator) or plant state (extended)

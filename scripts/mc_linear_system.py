@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--warm-start", action="store_true", help="tmpc_mc_set_warm_start: previous working set first")
     ap.add_argument("--timing", action="store_true", help="per-solve device times (tmpc_set_solve_timing): the max / quantiles / median "
                                                           "results_linear_system.py:305-315 prints")
+    ap.add_argument("--device-rng", action="store_true", help="draw the realisations on the device (tmpc_mc_set_device_rng, Philox keyed "
+                                                              "by the global trajectory index) instead of uploading them")
     ap.add_argument("--host-loop", action="store_true", help="state machines in numpy on the host instead of on the device")
     ap.add_argument("--reference-streams", action="store_true",
                     help="replay the reference's own random streams (seeds 679/347/124 consumed in its loop order, "
@@ -57,7 +59,8 @@ def main():
         pi = np.repeat(np.arange(len(p_loss)), args.n_mc)
     else:
         table, pi = montecarlo.mc_sweep(mpc, model, p_loss, args.n_mc, args.T, args.ref, rank=rank, world=world,
-                                        extended=args.extended, device=device, on_device=not args.host_loop, warm_start=args.warm_start, timing=args.timing and not args.host_loop)
+                                        extended=args.extended, device=device, on_device=not args.host_loop, warm_start=args.warm_start, timing=args.timing and not args.host_loop,
+                                        device_rng=args.device_rng)
     dt = time.time() - t0
     if rank == 0:
         n = len(pi)
