@@ -65,6 +65,9 @@ struct tmpc_handle {
     double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
     uint8_t *d_var = nullptr;
     int32_t *d_st = nullptr, *d_it = nullptr;
+    // (s, lambda) of every resident wave at its hand-over to the refinement (DeviceQP::save)
+    double *save_buf = nullptr;
+    size_t save_bytes = 0;
     // per-solve durations (tmpc_set_solve_timing): one tick count per instance of the last call
     int want_ticks = 0;
     int64_t ticks_cap = 0, ticks_n = 0;
@@ -118,6 +121,7 @@ int upload_common(tmpc_handle *h, Variant &v, const tmpc_problem &p, tmpc::Devic
     d.always_infeasible = c.always_infeasible ? 1 : 0;
     d.dbg = nullptr;
     d.ticks = nullptr;
+    d.save = nullptr;
     int rc;
     if ((rc = upload(h, v, Hs.data(), Hs.size(), &d.Hs))) return rc;
     if ((rc = upload(h, v, Hinv.data(), Hinv.size(), &d.Hinv))) return rc;
@@ -421,6 +425,19 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
                                           xu_ss, x_nom, status, iters, h->stream));
             continue;
         }
+        {
+            // one save slot per resident wave (at most 8 per CU), sized for this variant's row sides
+            const size_t rs = static_cast<size_t>(2 * v.shape.dp + v.shape.ds + 2 * v.shape.cp + v.shape.cs);
+            const size_t need = static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(double);
+            if (need > h->save_bytes) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                if (h->save_buf) (void)hipFree(h->save_buf);
+                h->save_buf = nullptr; h->save_bytes = 0;
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->save_buf), need));
+                h->save_bytes = need;
+            }
+            v.d.save = h->save_buf;
+        }
         HIP_TRY(h, tmpc::launch_solve(v.d, v.shape, k, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status,
                                       iters, ws ? ws[k] : nullptr, ws ? ws[k] : nullptr, &h->wc, h->n_cu, h->stream));
     }
@@ -534,7 +551,7 @@ void tmpc_destroy(tmpc_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
     {
-        void *wsp[] = {h->blk_ws, h->mc_arena, h->wc.ring, h->d_ticks};
+        void *wsp[] = {h->blk_ws, h->mc_arena, h->wc.ring, h->d_ticks, h->save_buf};
         for (void *q2 : wsp) if (q2) (void)hipFree(q2);
     }
     for (int k = 0; k < 2; ++k)

@@ -431,6 +431,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         wave_lds_fence();
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
+#ifdef TMPC_ITERS_TOTAL
+        int n_reruns = 0, n_rounds = 0;
+#endif
         const long long t_begin = qp.ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
 #ifdef TMPC_STAMPS
         long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -536,6 +539,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         }
         STAMP(0);
         bool try_warm = warm_m > 0 && warm_m <= WCAP;
+        int resume_it = -1;        // >= 0: continue the interior-point phase at this iteration from the saved (s, lambda)
+        double *const save = qp.save ? qp.save + (static_cast<size_t>(blockIdx.x) * WPB + wave) * (2 * RS * WAVE) : nullptr;
         bool h_valid = true;
         int ws_m = 0;
         if (st == TMPC_STATUS_MAX_ITER)
@@ -554,7 +559,29 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 // -------------------------------------------------------- interior point
                 double s[RS], lam[RS], rs[RS];
                 double *rpw = hw;       // carried primal residual, [side][lane], in the region of h
-                {
+                int it0 = 0;
+                if (resume_it >= 0) {
+                    // the refinement did not certify its working set: on with the interior-point iteration from the iterate of
+                    // the hand-over (z is still in LDS, (s, lambda) come back from the wave's save slot, r_p is formed anew)
+                    if (!h_valid) { compute_h(); h_valid = true; }
+                    coords_lds<SH>(Psi, zv, czv, lane);
+                    wave_lds_fence();
+                    (void)raw_slacks(s);
+                    h_valid = false;
+#pragma unroll
+                    for (int i = 0; i < RS; ++i) {
+                        const bool vl = valid(i);
+                        const double raw = s[i];
+                        const double sv = save[i * WAVE + lane], lv = save[(RS + i) * WAVE + lane];
+                        s[i] = vl ? sv : 1.0;
+                        lam[i] = vl ? lv : 0.0;
+                        rpw[i * WAVE + lane] = vl ? sv - raw : 0.0;
+                        rs[i] = 1.0;
+                    }
+                    wave_lds_fence();
+                    it0 = resume_it;
+                    resume_it = -1;
+                } else {
                     if (!h_valid) { compute_h(); h_valid = true; }
                     unconstrained_minimiser();
                     const double smin = wave_min(raw_slacks(s));
@@ -571,7 +598,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     }
                     wave_lds_fence();
                 }
-                for (int it = 0; it < qp.max_iter; ++it) {
+                for (int it = it0; it < qp.max_iter; ++it) {
                     it_done = it;
                     STAMP(9);
                     TMPC_REFRESH();
@@ -900,6 +927,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 TMPC_REFRESH();
 #pragma unroll
                 for (int i = 0; i < RS; ++i) { inW[i] = valid(i) && (lam[i] > s[i]); yall[i] = lam[i]; }
+                if (save != nullptr && want_polish) {
+#pragma unroll
+                    for (int i = 0; i < RS; ++i) { save[i * WAVE + lane] = s[i]; save[(RS + i) * WAVE + lane] = lam[i]; }
+                }
             }
             if (!want_polish) break;
             // ------------------------------------------------ active-set refinement
@@ -916,6 +947,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 if (lane < NV) zpv[lane] = zv[lane];
                 wave_lds_fence();
                 for (int round = 0; round < 10 && !ok; ++round) {
+#ifdef TMPC_ITERS_TOTAL
+                    ++n_rounds;
+#endif
                     // compact the working set: W[0..m)
                     TMPC_REFRESH();
                     int m = 0;
@@ -1155,6 +1189,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (try_warm) { try_warm = false; continue; }          // the handed-in set did not certify: cold interior-point start
             if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
             try_tol *= 1e-2;
+            if (save != nullptr) resume_it = it_done;
+#ifdef TMPC_ITERS_TOTAL
+            ++n_reruns;
+#endif
         }
         if (st == TMPC_STATUS_MAX_ITER) {
             // iteration cap: if the iterate still violates the constraints, call it infeasible
@@ -1214,7 +1252,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 wave_lds_fence();
             }
         }
+#ifdef TMPC_ITERS_TOTAL
+        if (lane == 0) { status[b] = st; iters[b] = it_done + 100 * n_reruns + 10000 * n_rounds; }   // diagnostic build: re-runs and refinement rounds folded in
+#else
         if (lane == 0) { status[b] = st; iters[b] = it_done; }
+#endif
         if (qp.ticks && lane == 0) qp.ticks[b] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()) - t_begin;
 #ifdef TMPC_STAMPS
         STAMP(8);
