@@ -946,7 +946,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 double *zpv = dzav;                       // the refinement's iterate
                 if (lane < NV) zpv[lane] = zv[lane];
                 wave_lds_fence();
-                for (int round = 0; round < 10 && !ok; ++round) {
+                // (continuing the interior-point phase costs a third of a round per iteration: the first attempt gives up early)
+                const int max_rounds = (try_tol == qp.tol && save != nullptr && !try_warm) ? 4 : 10;
+                for (int round = 0; round < max_rounds && !ok; ++round) {
 #ifdef TMPC_ITERS_TOTAL
                     ++n_rounds;
 #endif
