@@ -165,19 +165,37 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
     const int rs = bq.row_start[(2 * j2) >> 4];   // rows below do not reach this column tile (staircase): not loaded
     const v2d zero2 = {0.0, 0.0};
     int r = bq.nz4 + part;                 // general rows; the initial-state rows [0, nz4) follow below
-    for (; r + 7 * PARTS < nc; r += 8 * PARTS) {
-        v2d g[8];
-        double xa[8], xb[8];
+    if constexpr (NV2 >= WAVE) {
+        // a wave = one row part (T = 8): sixteen rows per trip, their weights va / vb fetched by sixteen lanes in one gather each
+        // and handed round by v_readlane (a load per row and lane would triple the vector-memory instructions of the pass)
+        for (; r + 15 * PARTS < nc; r += 16 * PARTS) {
+            const int rl = r + (tid & 15) * PARTS;
+            const double xal = va[rl], xbl = vb[rl];
+            v2d g[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
-            xa[k] = va[r + k * PARTS];
-            xb[k] = vb[r + k * PARTS];
+            for (int k = 0; k < 16; ++k) g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
+#pragma unroll
+            for (int k = 0; k < 16; k += 2) {
+                const double xa0 = readlane_d(xal, k), xb0 = readlane_d(xbl, k), xa1 = readlane_d(xal, k + 1), xb1 = readlane_d(xbl, k + 1);
+                a0 += g[k] * xa0; b0 += g[k] * xb0;
+                a1 += g[k + 1] * xa1; b1 += g[k + 1] * xb1;
+            }
         }
+    } else {
+        for (; r + 7 * PARTS < nc; r += 8 * PARTS) {           // several row parts per wave: eight rows in flight, weights per lane
+            v2d g[8];
+            double xa[8], xb[8];
 #pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-            a0 += g[k] * xa[k]; b0 += g[k] * xb[k];
-            a1 += g[k + 1] * xa[k + 1]; b1 += g[k + 1] * xb[k + 1];
+            for (int k = 0; k < 8; ++k) {
+                g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
+                xa[k] = va[r + k * PARTS];
+                xb[k] = vb[r + k * PARTS];
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k += 2) {
+                a0 += g[k] * xa[k]; b0 += g[k] * xb[k];
+                a1 += g[k + 1] * xa[k + 1]; b1 += g[k + 1] * xb[k + 1];
+            }
         }
     }
     for (; r < nc; r += PARTS) {

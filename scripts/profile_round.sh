@@ -27,3 +27,9 @@ for cfg in config3 config5; do
   python3 scripts/pmc_summary.py solve_ gpurun_out/pmc_${tag}_${cfg}_a gpurun_out/pmc_${tag}_${cfg}_b > gpurun_out/pmc_${tag}_${cfg}_summary.txt
   cat gpurun_out/pmc_${tag}_${cfg}_summary.txt
 done
+# summaries written here, on the box, from this run's files only (what gets copied into profiles/)
+python3 scripts/trace_summary.py gpurun_out/prof_$tag > gpurun_out/summ_${tag}_bench_kernel_trace_summary.txt
+for cfg in config3 config5; do python3 scripts/trace_summary.py gpurun_out/prof_${tag}_$cfg > gpurun_out/summ_${tag}_${cfg}_kernel_trace_summary.txt; done
+cp gpurun_out/pmc_${tag}_summary.txt gpurun_out/summ_${tag}_bench_pmc_summary.txt
+for cfg in config3 config5; do cp gpurun_out/pmc_${tag}_${cfg}_summary.txt gpurun_out/summ_${tag}_${cfg}_pmc_summary.txt; done
+
