@@ -187,7 +187,7 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     auto put_side = [&](int side, int lane, int row) {
         const size_t sl = static_cast<size_t>(side) * 64 + lane;
         g0p[sl] = c.g0s[row];
-        for (int j = 0; j < nx; ++j) Esp[sl * nx + j] = c.Es(row, j);
+        for (int j = 0; j < nx; ++j) Esp[static_cast<size_t>(j) * RS * 64 + sl] = c.Es(row, j);
         vmask[lane] |= 1u << side;
         row_of[sl] = row;
     };

@@ -34,7 +34,7 @@ struct DeviceQP {
     const double *F1s;    // [nv][nx]
     const double *F2s;    // [nv][nx]
     const double *g0p;    // [RS*64]       right-hand side offsets per row side, slot layout (padding: 1); RS = 2 DP + DS + 2 CP + CS
-    const double *Esp;    // [RS*64][nx]   right-hand side dependence on x_k, slot layout
+    const double *Esp;    // [nx][RS*64]   right-hand side dependence on x_k, slot layout, one plane per state (coalesced per lane)
     const uint32_t *vmask;   // [64]       bit i of entry l: row side i of lane l is a real row
     const int32_t *row_of;   // [RS*64]    row (order of Condensed::Gs) behind each row side, -1: padding
     const double *gp0;    // [npar]

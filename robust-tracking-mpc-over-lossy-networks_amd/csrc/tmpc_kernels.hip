@@ -436,7 +436,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 #endif
         const long long t_begin = qp.ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
 #ifdef TMPC_STAMPS
-        long long tph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_amdgcn_s_memtime();
 #endif
         bool infeasible_par = qp.always_infeasible != 0;
@@ -457,14 +457,22 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         // primal residual in the same LDS region (it never reads h), so h is formed again before anything that needs it.
         auto compute_h = [&]() {
             TMPC_REFRESH();
+            // h = g0 + E x_k: one plane of E per state, the RS loads of a plane are issued together (nx round trips to L2
+            // instead of RS nx: this runs at set-up and again at every hand-over, its LDS region holds r_p in between)
+            double hv[RS];
+#pragma unroll
+            for (int i = 0; i < RS; ++i) hv[i] = qp.g0p[i * WAVE + lane];
+            for (int c = 0; c < nx; ++c) {
+                const double xc = xin[c];
+                const double *__restrict__ Ec = qp.Esp + static_cast<size_t>(c) * (RS * WAVE) + lane;
+#pragma unroll
+                for (int i = 0; i < RS; ++i) hv[i] = fma(Ec[i * WAVE], xc, hv[i]);
+            }
             double hmax = 1.0;
 #pragma unroll
             for (int i = 0; i < RS; ++i) {
-                const int sl = i * WAVE + lane;
-                double v = qp.g0p[sl];
-                for (int c = 0; c < nx; ++c) v += qp.Esp[sl * nx + c] * xin[c];
-                if (valid(i)) hmax = fmax(hmax, fabs(v));
-                hw[sl] = v;
+                if (valid(i)) hmax = fmax(hmax, fabs(hv[i]));
+                hw[i * WAVE + lane] = hv[i];
             }
             wave_lds_fence();
             return hmax;
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             for (int i = 0; i < RS; ++i) {
                                 const int sl = i * WAVE + lane;
                                 double hv = qp.g0p[sl];
-                                for (int c = 0; c < nx; ++c) hv += qp.Esp[sl * nx + c] * xin[c];
+                                for (int c = 0; c < nx; ++c) hv += qp.Esp[static_cast<size_t>(c) * (RS * WAVE) + sl] * xin[c];
                                 hl += hv * lam[i];
                             }
                             hl = wave_sum(hl);
@@ -986,6 +994,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         m += __popcll(bal);
                     }
                     wave_lds_fence();
+                    STAMP(10);
                     if (m > WCAP) break;
                     if (m == 0) {
                         if (lane < NV) {
@@ -1026,6 +1035,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             T[i * WCAP + k] = v;
                         }
                         wave_lds_fence();
+                        STAMP(11);
                         // S = G_W T, its LDL' and the Newton steps, compiled for working sets of at most 12 rows (the common case: the
                         // fully unrolled elimination costs MC^2 / 2 broadcasts whatever m is) and for the full capacity
                         auto solve_working_set = [&]<int MC>(std::integral_constant<int, MC>) -> bool {
@@ -1056,6 +1066,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             double bdummy = 0.0;
                             if (!rows_factor<MC>(srow, bdummy, sdinv, lane)) return false;
                         }
+                        STAMP(12);
                         // proximal Newton steps on the KKT system of the working set (at most twelve -- nearly parallel working rows need them --; they stop once a step
                         // no longer moves the iterate)
                         for (int stp = 0; stp < 12; ++stp) {
@@ -1110,6 +1121,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         else fact_ok = solve_working_set(std::integral_constant<int, WCAP>{});
                         if (!fact_ok) break;
                     }
+                    STAMP(13);
                     // ---- verify: primal feasibility on all rows, sign of y on W
                     TMPC_REFRESH();
                     double ymax = 1.0;
@@ -1152,6 +1164,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         });
                     }
                     wave_lds_fence();
+                    STAMP(14);
 #ifdef TMPC_DEBUG_PRINT
                     if (lane == 0 && b < 2) {
                         printf("b %lld warm %d tol %.1e it %d round %d m %d nviol %d nneg %d nloose %d ymax %.3e W:", (long long)b, (int)try_warm, try_tol, it_done, round, m, nviol, nneg, nloose, ymax);
@@ -1262,7 +1275,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         if (qp.ticks && lane == 0) qp.ticks[b] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()) - t_begin;
 #ifdef TMPC_STAMPS
         STAMP(8);
-        if (b == 0 && lane == 0 && qp.dbg) { for (int p_ = 0; p_ < 12; ++p_) qp.dbg[p_] = tph[p_]; }
+        if (b == 0 && lane == 0 && qp.dbg) { for (int p_ = 0; p_ < 16; ++p_) qp.dbg[p_] = tph[p_]; }
 #endif
         wave_lds_fence();
     }
