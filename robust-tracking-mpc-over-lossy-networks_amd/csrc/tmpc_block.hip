@@ -985,6 +985,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             if (tid < m) S[tid * LDSS + tid] += 1e-11 * dmax;
                             if (!block_chol<SH::BW>(S, LDSS, m, dinv, red + 32, tid)) break;
                             block_invert<SH::BW>(S, LDSS, m, dinv, tid);
+                            double dz_prev = 0.0;
                             for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
                                 {
@@ -1022,7 +1023,11 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                                 if (tid < m) yv[tid] += dyv[tid];
                                 double dum = 0.0;
                                 block_reduce3<SH::BW, OpMax, OpMax, OpMax>(dzl, zl, dum, red, wave, lane);
-                                if (stp >= 1 && dzl <= 1e-14 * zl) break;        // the step no longer moves the iterate
+                                if (stp >= 1) {       // the step no longer moves the iterate, or what is left after it cannot (tmpc_kernels.hip)
+                                    const double rho = dzl / fmax(dz_prev, 1e-300);
+                                    if (dzl <= 1e-14 * zl || (rho < 0.5 && dzl * rho <= 0.5e-15 * zl)) break;
+                                }
+                                dz_prev = dzl;
                             }
                         }
                         // ---- verify: primal feasibility on all rows, sign of y on W

@@ -1069,6 +1069,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         STAMP(12);
                         // proximal Newton steps on the KKT system of the working set (at most twelve -- nearly parallel working rows need them --; they stop once a step
                         // no longer moves the iterate)
+                        double dz_prev = 0.0;
                         for (int stp = 0; stp < 12; ++stp) {
                             TMPC_REFRESH();
                             // r1 = Hs zp + q + G_W' y   (lane i -> entry i)
@@ -1110,8 +1111,15 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 dzl = fabs(v);
                             }
                             wave_lds_fence();
-                            const double dzn = wave_max(dzl), zn = wave_max(fabs(zl));
-                            if (stp >= 1 && dzn <= 1e-14 * fmax(zn, 1.0)) break;
+                            const double dzn = wave_max(dzl), zn = fmax(wave_max(fabs(zl)), 1.0);
+                            // the steps contract linearly (ratio ~ delta / lambda_min(S), 1e-11 for well separated rows): stop
+                            // when this step no longer moves the iterate, or when what is left after it -- dz rho / (1 - rho)
+                            // with the observed ratio rho -- cannot
+                            if (stp >= 1) {
+                                const double rho = dzn / fmax(dz_prev, 1e-300);
+                                if (dzn <= 1e-14 * zn || (rho < 0.5 && dzn * rho <= 0.5e-15 * zn)) break;
+                            }
+                            dz_prev = dzn;
                         }
                             return true;
                         };
