@@ -525,10 +525,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 
         // Control flow of one instance.  The interior-point phase and the active-set refinement never hold registers at
         // the same time: at the hand-over the working set {lambda_i > s_i} and its multipliers are all the refinement
-        // takes from (s, lambda).  Should the refinement fail to certify its set (rare: 0 of 600 fixture instances at
-        // N = 10, 5 of 600 at N = 20), the interior-point phase is RE-RUN from its start with a 100 x tighter hand-over
-        // tolerance -- the iteration is deterministic, so this retraces the same iterates and continues past the first
-        // hand-over point, exactly what carrying (s, lambda) across the refinement would give.
+        // takes from (s, lambda), which go to the wave's save slot in HBM (DeviceQP::save).  Should the refinement fail to
+        // certify its set (rare: 3 of the 4096 bench instances), the interior-point phase CONTINUES from the saved iterate with
+        // a 100 x tighter hand-over tolerance (without a save slot it is re-run from its start, which retraces the same iterates).
         // With a working set handed in by the caller (ws_in: the previous time step's, closed loop) the refinement is
         // tried on it BEFORE any interior-point iteration; it is exact or rejected, never approximate.
         double try_tol = qp.tol;
