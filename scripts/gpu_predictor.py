@@ -61,3 +61,9 @@ if os.path.exists(dbg):
     for k in sorted(set(rounds.tolist())):
         m = rounds == k
         print(f"  rounds {k:2d}: n {m.sum():4d} mean time {t2[m].mean():6.1f} us, max {t2[m].max():6.1f}, re-runs {reruns[m].sum()}")
+# trivially cheap proxies from (x_k, ref) alone
+e = X - R
+prox = {"|pos err|": np.abs(e[:, 0]), "|e|_2": np.linalg.norm(e, axis=1), "|x|_inf scaled": np.max(np.abs(X) / np.array([5, 5, .3, 2.0]), axis=1),
+        "|q|_inf": np.abs(q).max(axis=1), "|z_unc|_inf": np.abs(z).max(axis=1), "|u0_unc|": np.abs(z[:, 0])}
+for k, f in prox.items():
+    print(f"  proxy {k:16s} corr with iters {np.corrcoef(f, it)[0,1]:+.3f}  with time {np.corrcoef(f, tm)[0,1]:+.3f}  makespan if sorted by it {makespan(tm[np.argsort(-f)]):.0f}")
