@@ -66,7 +66,7 @@ struct tmpc_handle {
     uint8_t *d_var = nullptr;
     int32_t *d_st = nullptr, *d_it = nullptr;
     // (s, lambda) of every resident wave at its hand-over to the refinement (DeviceQP::save)
-    double *save_buf = nullptr;
+    float *save_buf = nullptr;
     size_t save_bytes = 0;
     // per-solve durations (tmpc_set_solve_timing): one tick count per instance of the last call
     int want_ticks = 0;
@@ -428,7 +428,7 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
         {
             // one save slot per resident wave (at most 8 per CU), sized for this variant's row sides
             const size_t rs = static_cast<size_t>(2 * v.shape.dp + v.shape.ds + 2 * v.shape.cp + v.shape.cs);
-            const size_t need = static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(double);
+            const size_t need = static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(float);
             if (need > h->save_bytes) {
                 HIP_TRY(h, hipStreamSynchronize(h->stream));
                 if (h->save_buf) (void)hipFree(h->save_buf);

@@ -47,7 +47,7 @@ struct DeviceQP {
     const double *A;      // [nx][nx]
     const double *B;      // [nx][nu]
     long long *dbg;       // diagnostic builds only (TMPC_STAMPS); nullptr otherwise
-    double *save;         // [resident waves][2][RS][64] or nullptr: (s, lambda) at the hand-over to the refinement, so that a
+    float *save;          // [resident waves][2][RS][64] or nullptr: (s, lambda) at the hand-over to the refinement, so that a
                           // refinement that fails to certify its set continues the interior-point phase instead of repeating it
     long long *ticks;     // [B] or nullptr: time the instance spent in its wave / workgroup, in s_memrealtime ticks (10 ns)
 };

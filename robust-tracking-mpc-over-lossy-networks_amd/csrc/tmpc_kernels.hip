@@ -432,7 +432,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
 #ifdef TMPC_ITERS_TOTAL
-        int n_reruns = 0, n_rounds = 0;
+        int n_reruns = 0, n_rounds = 0, amb_level = 0;
 #endif
         const long long t_begin = qp.ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
 #ifdef TMPC_STAMPS
@@ -547,7 +547,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         STAMP(0);
         bool try_warm = warm_m > 0 && warm_m <= WCAP;
         int resume_it = -1;        // >= 0: continue the interior-point phase at this iteration from the saved (s, lambda)
-        double *const save = qp.save ? qp.save + (static_cast<size_t>(blockIdx.x) * WPB + wave) * (2 * RS * WAVE) : nullptr;
+        float *const save = qp.save ? qp.save + (static_cast<size_t>(blockIdx.x) * WPB + wave) * (2 * RS * WAVE) : nullptr;
+        bool saved = false;        // (s, lambda) of the last hand-over are in the save slot
         bool h_valid = true;
         int ws_m = 0;
         if (st == TMPC_STATUS_MAX_ITER)
@@ -579,7 +580,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     for (int i = 0; i < RS; ++i) {
                         const bool vl = valid(i);
                         const double raw = s[i];
-                        const double sv = save[i * WAVE + lane], lv = save[(RS + i) * WAVE + lane];
+                        double sv = static_cast<double>(save[i * WAVE + lane]);
+                        const double lv = static_cast<double>(save[(RS + i) * WAVE + lane]);
+                        // the rounding of s must not come back as a primal residual s - (h - G z): where the parked slack is the
+                        // raw slack to single precision, the raw slack is the better copy
+                        if (raw > 0.0 && fabs(sv - raw) <= 2.5e-7 * sv) sv = raw;
                         s[i] = vl ? sv : 1.0;
                         lam[i] = vl ? lv : 0.0;
                         rpw[i * WAVE + lane] = vl ? sv - raw : 0.0;
@@ -934,9 +939,37 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 TMPC_REFRESH();
 #pragma unroll
                 for (int i = 0; i < RS; ++i) { inW[i] = valid(i) && (lam[i] > s[i]); yall[i] = lam[i]; }
-                if (save != nullptr && want_polish) {
+#ifdef TMPC_ITERS_TOTAL
+                if (want_polish && amb_level == 0) {
+                    // diagnostic: how clearly does (s, lambda) separate the working set?  level k: some row has lambda / s within 10^k of 1
+                    amb_level = 9;
 #pragma unroll
-                    for (int i = 0; i < RS; ++i) { save[i * WAVE + lane] = s[i]; save[(RS + i) * WAVE + lane] = lam[i]; }
+                    for (int i = 0; i < RS; ++i) {
+                        if (valid(i)) {
+                            const double lr = fabs(log10(lam[i] / s[i]));
+                            const int k = lr < 1.0 ? 1 : (lr < 2.0 ? 2 : (lr < 3.0 ? 3 : (lr < 4.0 ? 4 : (lr < 6.0 ? 6 : 9))));
+                            amb_level = k < amb_level ? k : amb_level;
+                        }
+                    }
+                    amb_level = -static_cast<int>(wave_max(-static_cast<double>(amb_level)));
+                }
+#endif
+                if (save != nullptr && want_polish) {
+                    // (s, lambda) are parked only when they do not separate the working set clearly -- some row with lambda / s
+                    // within two decades of 1: every re-run but 3 of 30 720 closed-loop instances at N = 10 (13 at N = 20) comes
+                    // from that fifth of the instances -- and in single precision: the continuation starts from an interior point
+                    // 6e-8 away from the iterate, which an interior-point iteration does not notice
+                    bool amb = false;
+#pragma unroll
+                    for (int i = 0; i < RS; ++i) amb = amb || (valid(i) && lam[i] < 100.0 * s[i] && s[i] < 100.0 * lam[i]);
+                    saved = __ballot(amb) != 0ull;
+                    if (saved) {
+#pragma unroll
+                        for (int i = 0; i < RS; ++i) {
+                            save[i * WAVE + lane] = static_cast<float>(s[i]);
+                            save[(RS + i) * WAVE + lane] = static_cast<float>(lam[i]);
+                        }
+                    }
                 }
             }
             if (!want_polish) break;
@@ -954,7 +987,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 if (lane < NV) zpv[lane] = zv[lane];
                 wave_lds_fence();
                 // (continuing the interior-point phase costs a third of a round per iteration: the first attempt gives up early)
-                const int max_rounds = (try_tol == qp.tol && save != nullptr && !try_warm) ? 4 : 10;
+                const int max_rounds = (try_tol == qp.tol && saved && !try_warm) ? 4 : 10;
                 for (int round = 0; round < max_rounds && !ok; ++round) {
 #ifdef TMPC_ITERS_TOTAL
                     ++n_rounds;
@@ -1211,7 +1244,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (try_warm) { try_warm = false; continue; }          // the handed-in set did not certify: cold interior-point start
             if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
             try_tol *= 1e-2;
-            if (save != nullptr) resume_it = it_done;
+            if (saved) resume_it = it_done;        // (else the phase is re-run from its start: exact, slower, rare)
+            saved = false;
 #ifdef TMPC_ITERS_TOTAL
             ++n_reruns;
 #endif
@@ -1275,7 +1309,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             }
         }
 #ifdef TMPC_ITERS_TOTAL
-        if (lane == 0) { status[b] = st; iters[b] = it_done + 100 * n_reruns + 10000 * n_rounds; }   // diagnostic build: re-runs and refinement rounds folded in
+        if (lane == 0) { status[b] = st; iters[b] = it_done + 100 * n_reruns + 10000 * n_rounds + 1000000 * amb_level; }   // diagnostic build: re-runs and refinement rounds folded in
 #else
         if (lane == 0) { status[b] = st; iters[b] = it_done; }
 #endif
