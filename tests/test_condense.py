@@ -154,6 +154,19 @@ def test_closed_loop_setters_validate_their_arguments(hip_lib):
     assert L.tmpc_mc_set_warm_start(h.ptr, 1) == 0 and L.tmpc_mc_set_warm_start(h.ptr, 0) == 0
     assert L.tmpc_mc_set_capture(h.ptr, 3) == 0 and L.tmpc_mc_set_capture(h.ptr, -1) == 0
     assert L.tmpc_mc_get_capture(h.ptr, 5, None, None, None) == -1 and b"recorded" in L.tmpc_last_error(h.ptr)
+    # per-solve times, physics-rate error, device generator: settings are accepted, results need a run
+    assert L.tmpc_set_solve_timing(h.ptr, 1) == 0
+    ticks = np.zeros(4, dtype=np.int64)
+    assert L.tmpc_get_solve_ticks(h.ptr, 4, ticks.ctypes.data) == -1 and b"timed" in L.tmpc_last_error(h.ptr)
+    assert L.tmpc_mc_get_solve_ticks(h.ptr, 4, ticks.ctypes.data, None) == -1
+    assert L.tmpc_set_solve_timing(h.ptr, 0) == 0 and L.tmpc_set_solve_timing(None, 1) == -1
+    assert L.tmpc_mc_get_physics_error(h.ptr, 4, np.zeros(4).ctypes.data) == -1 and b"linear plant" in L.tmpc_last_error(h.ptr)
+    wb = np.array([1e-4, 2.7e-3, 3e-4, 4.3e-2])
+    assert L.tmpc_mc_set_device_rng(h.ptr, 1, 12345, 7, wb.ctypes.data) == 0 and L.tmpc_mc_set_device_rng(h.ptr, 0, 0, 0, None) == 0
+    # with the generator on, tmpc_mc_run takes NULL realisations (and still has no CPU path)
+    assert L.tmpc_mc_set_device_rng(h.ptr, 1, 1, 0, None) == 0
+    rc = L.tmpc_mc_run(h.ptr, 1, 1, 0, one.ctypes.data, one.ctypes.data, None, None, None, None, None, None, 0, None, None, None, None, None, None)
+    assert rc == -3
     hip_lib.destroy(h)
     # double integrator: the cart-pole plant needs nx = 4, nu = 1
     mpc2, _ = common.make_mpc("double_integrator", 5, False)
