@@ -337,6 +337,27 @@ def main():
                                   "note": "end to end incl. upload of the realisations and download of the statistics; warm = every "
                                           "solve first tries the working set of the trajectory's previous step in the exact refinement"}
         if world == 1 and not args.no_extras:
+            # two handles (two streams) taking turns over the same batches: a launch of 4096 ends with its slowest instance
+            # (two instances per resident wave), and the tail of one launch overlaps with the head of the next when it is
+            # on another stream -- the throughput a server sees that pipelines its batches.  `value` above stays the
+            # one-stream figure, whose kernel durations the roofline entry prices.
+            mpc_b, _ = workloads.make_controller("cartpole", 10, True, device=dev_index)
+            twin = [DeviceBatch(torch, dev, X[p_], R[p_], None, N, nu) for p_ in
+                    (np.random.default_rng(2100 + k).permutation(B) for k in range(NORD))]
+            hs, bs = (mpc._handle, mpc_b._handle), (batches, twin)
+            for k in range(2 * NORD):
+                bs[k % 2][k % NORD].solve(_native, hs[k % 2])
+            for h_ in hs:
+                _native.synchronize(h_)
+            tp = time.perf_counter()
+            for k in range(args.steps):
+                bs[k % 2][k % NORD].solve(_native, hs[k % 2])
+            for h_ in hs:
+                _native.synchronize(h_)
+            tp = time.perf_counter() - tp
+            out["pipelined"] = {"value": B * args.steps / tp, "unit": "solves/s", "handles": 2, "steps": args.steps,
+                                "ms_per_step": tp / args.steps * 1e3,
+                                "note": "same batches, two handles on their own streams taking turns (tails of successive launches overlap)"}
             out["config3"] = config3_extra()
             out["config5"] = config5_extra()
             # offline stage extra: support-function LPs over this workload's terminal set in one launch (tmpc_lp_batch)
