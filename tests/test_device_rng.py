@@ -74,3 +74,18 @@ def test_sweep_with_device_generator(hip_lib):
     host, _ = montecarlo.mc_sweep(mpc, w, p_loss, 6, 80, 0.5, seed=99, on_device=False, device_rng=True)
     np.testing.assert_allclose(dev[:, 0], host[:, 0], rtol=0, atol=1e-9)
     assert np.array_equal(dev[:, 1:], host[:, 1:]) and np.all(dev[:, 1] == 0)
+
+
+@pytest.mark.gpu
+def test_device_generator_other_state_dimension(hip_lib):
+    """nx = 2 (double integrator, free initial state): one Philox block per step carries theta, gamma and both disturbances."""
+    nb, T, seed = 64, 40, 7
+    mpc, w = common.make_mpc("double_integrator", 5, False, create=True)
+    p_loss = np.tile([0.0, 0.5], nb // 2)
+    ref = np.full(T, 2.0)
+    th, ga, dist = montecarlo.draw_realisations_philox(nb, T, w["w_bound"], seed=seed, first=0)
+    a = mpc.run_closed_loop(p_loss, ref, th, ga, dist)
+    b = mpc.run_closed_loop(p_loss, ref, device_rng=(seed, 0, w["w_bound"]))
+    for key in ("err2", "tube_violations", "not_optimal", "x_final"):
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert np.all(b["tube_violations"] == 0)
