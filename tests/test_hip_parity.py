@@ -355,3 +355,44 @@ def test_horizon_sweep_covers_the_kernel_shapes(hip_lib, oracle_lib, name, fixed
         np.testing.assert_allclose(out["xu_ss"][ok], ref["xu_ss"][ok], atol=ATOL_SS, rtol=0, err_msg=f"N={N}")
         np.testing.assert_allclose(out["x_nom"][ok], ref["x_nom"][ok], atol=1e-8, rtol=0, err_msg=f"N={N}")
     assert len(seen) >= 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [10, 20])
+def test_full_size_batch_65536(hip_lib, oracle_lib, N):
+    """BASELINE's full batch size through the wave kernel (N = 10: two waves per SIMD; N = 20, the reference's horizon,
+    results_linear_system.py:64: one wave per SIMD): perturbed closed-loop states, some of them outside the feasible set.
+    Size-independent properties on all 65536 instances -- every status is 0 / 2, optimal solutions respect the input box,
+    a permuted batch gives the permuted answer, the block kernel agrees on a slice -- and a 2048-instance sample against the oracle."""
+    S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))        # (x_hat, ref) pairs of closed loops
+    mpc, w = common.make_mpc("cartpole", N, True, create=True)
+    rng = np.random.default_rng(2024 + N)
+    B = 65536
+    idx = rng.integers(0, len(S), B)
+    X = S[idx, :4] + rng.uniform(-1, 1, (B, 4)) * 0.5 * w["w_bound"]
+    R = S[idx, 4:].copy()
+    R[:, 0] += rng.uniform(-0.5, 0.5, B)
+    big = mpc._solve(X, R, want_traj=False)
+    assert hip_lib.kernel_name(mpc._handle).startswith("tmpc::solve_kernel")
+    st = big["status"]
+    assert np.all((st == 0) | (st == 1) | (st == 2)) and np.mean(st == 1) < 1e-3 and np.mean(st == 0) > 0.5
+    good = st == 0
+    assert np.all(np.abs(big["u_nom"][good]) <= 10.0 + 1e-7)                 # U = [-10, 10] (results_linear_system.py:104-106)
+    assert np.all(np.isnan(big["u_nom"][st == 2]))
+    perm = rng.permutation(B)
+    again = mpc._solve(X[perm], R[perm], want_traj=False)
+    assert np.array_equal(again["status"], st[perm])
+    np.testing.assert_allclose(again["u_nom"][good[perm]], big["u_nom"][perm][good[perm]], rtol=0, atol=1e-9)
+    mpc.set_kernel_path("block")
+    blk = mpc._solve(X[:1024], R[:1024], want_traj=False)
+    mpc.set_kernel_path("auto")
+    both = (blk["status"] == 0) & good[:1024]
+    assert np.mean(blk["status"] == st[:1024]) > 0.995
+    np.testing.assert_allclose(blk["u_nom"][both], big["u_nom"][:1024][both], rtol=0, atol=1e-8)
+    sub = rng.choice(B, 2048, replace=False)
+    ref = Oracle(mpc._problem_dict()).solve(X[sub], R[sub])
+    # certified-optimal vs uncertified (status 1) may differ between the implementations on a few instances; infeasibility may not
+    assert np.array_equal(st[sub] == 2, ref["status"] == 2)
+    ok = (st[sub] == 0) & (ref["status"] == 0)
+    assert ok.sum() > 1000
+    np.testing.assert_allclose(big["u_nom"][sub][ok], ref["u_nom"][ok], rtol=0, atol=1e-8)
