@@ -110,6 +110,30 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
     return (t0 + t1) + (t2 + t3);
 }
 
+// The same for the row pair (r, r + 1), r even: 16-byte loads (an 8-byte access runs at 0.54 - 0.70 of the 16-byte rate, and
+// the row passes sit at the CU's L1 rate).  Initial-state rows go through row_dot.
+__device__ __forceinline__ void row_dot2(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v, const BlockQP &bq,
+                                         double &o0, double &o1) {
+    if (r < bq.nz4) { o0 = row_dot(Gcm, ncp, nv, r, v, bq); o1 = row_dot(Gcm, ncp, nv, r + 1, v, bq); return; }
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int n0 = bq.ncols[r], n1 = bq.ncols[r + 1];
+    nv = n0 > n1 ? n0 : n1;                 // (rows are ordered by their reach: the two mostly agree; the shorter one reads zeros)
+    const v2d *__restrict__ G2 = reinterpret_cast<const v2d *>(Gcm + r);
+    const size_t st = static_cast<size_t>(ncp) / 2;
+    v2d t0 = {0.0, 0.0}, t1 = {0.0, 0.0}, t2 = {0.0, 0.0}, t3 = {0.0, 0.0};
+    int j = 0;
+    for (; j + 8 <= nv; j += 8) {
+        v2d g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = G2[static_cast<size_t>(j + k) * st];
+        t0 += g[0] * v[j]; t1 += g[1] * v[j + 1]; t2 += g[2] * v[j + 2]; t3 += g[3] * v[j + 3];
+        t0 += g[4] * v[j + 4]; t1 += g[5] * v[j + 5]; t2 += g[6] * v[j + 6]; t3 += g[7] * v[j + 7];
+    }
+    for (; j < nv; ++j) t0 += G2[static_cast<size_t>(j) * st] * v[j];
+    const v2d t = (t0 + t1) + (t2 + t3);
+    o0 = t.x; o1 = t.y;
+}
+
 // sum_j Hm[j][c] v[j] + sum_k R[idx[k]][c] w[k] for column c = tid (valid for tid < NVP), by all threads: thread
 // (c, part) takes every (BT / NVP)-th term, eight loads in flight, the parts meet in LDS.  Hm (symmetric, [NVP][NVP]) or R
 // (rows of NVP) may be null.  With the columns alone (128 threads, four loads in flight) a 128-variable product costs
@@ -875,9 +899,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     BSTAMP(6);
                     // ---- P5: affine step statistics, corrector terms per row
                     double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
-                    for (int r = tid; r < ncp; r += BT) {
+                    auto p5_row = [&](int r, double gd) {
                         const bool valid = r < nc;
-                        const double gd = row_dot(Gcm, ncp, nv, r, dzav, bq);
                         const double sv = s_[r], lv = lam_[r], rp = rp_[r], d = d_[r];
                         const double rs = valid ? fast_rcp(sv) : 0.0;
                         const double dsa = valid ? (-rp - gd) : 0.0;
@@ -890,6 +913,12 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         w_[r] = w;
                         c1_[r] = w * rs;
                         rs_[r] = rs;
+                    };
+                    for (int r = 2 * tid; r < ncp; r += 2 * BT) {            // row pairs (ncp is a multiple of 64)
+                        double gd0, gd1;
+                        row_dot2(Gcm, ncp, nv, r, dzav, bq, gd0, gd1);
+                        p5_row(r, gd0);
+                        p5_row(r + 1, gd1);
                     }
                     block_reduce3<SH::BW, OpMax, OpSum, OpSum>(rho_aff, sb1, sb2, red, wave, lane);
                     const double aaff = rho_aff > 1.0 ? 1.0 / rho_aff : 1.0;
@@ -909,9 +938,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     om = fmin(fmax(om, 1e-4), 1e-2);
                     const double tau = 1.0 - om;
                     double rho = 0.0;
-                    for (int r = tid; r < ncp; r += BT) {
+                    auto p7_row = [&](int r, double gd) {
                         const bool valid = r < nc;
-                        const double gd = row_dot(Gcm, ncp, nv, r, dzv, bq);
                         const double sv = s_[r], lv = lam_[r], rp = rp_[r], rs = rs_[r];
                         const double dsk = valid ? (-rp - gd) : 0.0;
                         const double rc = sv * lv + w_[r] - smu;
@@ -921,6 +949,12 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         gdz_[r] = gd;
                         ds_[r] = dsk;
                         dl_[r] = dlk;
+                    };
+                    for (int r = 2 * tid; r < ncp; r += 2 * BT) {
+                        double gd0, gd1;
+                        row_dot2(Gcm, ncp, nv, r, dzv, bq, gd0, gd1);
+                        p7_row(r, gd0);
+                        p7_row(r + 1, gd1);
                     }
                     rho = block_reduce1<SH::BW, OpMax>(rho, red, wave, lane);
                     const double alpha = rho > tau ? tau / rho : 1.0;
