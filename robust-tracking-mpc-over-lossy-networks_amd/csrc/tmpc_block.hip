@@ -779,13 +779,18 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
         }
         __syncthreads();
         double smin_l = INFINITY;
-        for (int r = tid; r < ncp; r += BT) {
-            const double gz = row_dot(Gcm, ncp, nv, r, zv, bq);
-            const double sv = h_[r] - gz;
-            gz_[r] = gz;
-            s_[r] = sv;
-            lam_[r] = 0.0;
-            if (r < nc) smin_l = fmin(smin_l, sv);
+        for (int r2 = 2 * tid; r2 < ncp; r2 += 2 * BT) {            // row pairs (row_dot2)
+            double gzp[2];
+            row_dot2(Gcm, ncp, nv, r2, zv, bq, gzp[0], gzp[1]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int r = r2 + q;
+                const double sv = h_[r] - gzp[q];
+                gz_[r] = gzp[q];
+                s_[r] = sv;
+                lam_[r] = 0.0;
+                if (r < nc) smin_l = fmin(smin_l, sv);
+            }
         }
         block_reduce3<SH::BW, OpMax, OpMax, OpMin>(qn_l, hn_l, smin_l, red, wave, lane);
         const double qn = qn_l, hn = hn_l, smin = smin_l;
@@ -1071,10 +1076,15 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         if (tid < m) yall_[Widx[tid]] = yv[tid];
                         __syncthreads();
                         double nviol = 0.0, nneg = 0.0, nloose = 0.0;
-                        for (int r = tid; r < ncp; r += BT) {
+                        for (int r2 = 2 * tid; r2 < ncp; r2 += 2 * BT) {
+                          double gzp[2];
+                          row_dot2(Gcm, ncp, nv, r2, zpv, bq, gzp[0], gzp[1]);
+#pragma unroll
+                          for (int q = 0; q < 2; ++q) {
+                            const int r = r2 + q;
                             const bool valid = r < nc;
                             const double hk = h_[r];
-                            const double rr = row_dot(Gcm, ncp, nv, r, zpv, bq) - hk;
+                            const double rr = gzp[q] - hk;
                             rr_[r] = rr;
                             const bool in = inW_[r] != 0;
                             const double hi = fmax(fabs(hk), 1.0);
@@ -1086,6 +1096,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             nloose += loose ? 1.0 : 0.0;
                             if (neg) { inW_[r] = 0; yall_[r] = 0.0; }
                             if (viol) { inW_[r] = 1; yall_[r] = 0.0; }
+                          }
                         }
                         block_reduce3<SH::BW, OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
                         // rows of W off their bound with nothing left to correct: not converged, give up (see tmpc_kernels.hip)
