@@ -62,12 +62,26 @@ def host_cores():
     return cores
 
 
+TRAFFIC_PROFILE = os.path.join("profiles", "r03_bench_pmc_summary.txt")
+
+
 def measured_traffic(kernel_name):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot run inside this process);
-    only reported when the profile was taken on the very kernel instantiation the library runs now."""
+    """HBM bytes per launch of `kernel_name` from the PMC summary committed under profiles/ (rocprofv3 cannot run inside
+    this process): FETCH_SIZE + WRITE_SIZE of separate --pmc passes of this very command, in KB as rocprofv3 reports them
+    (scripts/profile_round.sh -> scripts/pmc_summary.py writes the file).  None unless the summary is about the kernel
+    instantiation the library runs now.  FETCH_SIZE is taken at face value: the x2 of MI355X_MICROARCH.md is calibrated on
+    16-byte-per-lane streaming reads, these are 8-byte-per-lane reads of L2-resident model data."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
-        return t.get("hbm_bytes_per_launch") if t.get("kernel") == kernel_name else None
+        want = kernel_name.replace(" ", "")
+        cur, vals = None, {}
+        for line in open(os.path.join(ROOT, TRAFFIC_PROFILE)):
+            if line.startswith("=="):
+                cur = line[2:].strip().replace(" ", "")
+            elif cur == want:
+                f = line.split()
+                if len(f) >= 2 and f[0] in ("FETCH_SIZE", "WRITE_SIZE"):
+                    vals[f[0]] = float(f[1]) * 1024.0
+        return vals["FETCH_SIZE"] + vals["WRITE_SIZE"] if len(vals) == 2 else None
     except Exception:
         return None
 
@@ -157,8 +171,12 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # TMPC_BENCH_FORCE_PG=1: a one-rank run takes the multi-rank code path as well (process group, device-side gather,
+    # barrier) -- the RCCL rehearsal that fits a one-GPU box (tests/test_nccl_single_rank.py)
+    use_pg = world > 1 or os.environ.get("TMPC_BENCH_FORCE_PG", "0") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -227,7 +245,7 @@ def main():
     def fence():
         _native.synchronize(h)
         torch.cuda.synchronize()
-        if world > 1:
+        if use_pg:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -237,7 +255,7 @@ def main():
         stats = torch.stack([batch.st, batch.it], dim=1).contiguous()
         if backend != "nccl":
             stats = stats.cpu()
-        return montecarlo.gather_statistics(stats, world * B, rank, world)
+        return montecarlo.gather_statistics(stats, world * B, rank, world, force_collective=use_pg)
 
     for i in range(args.warmup):
         batches[i % NORD].solve(_native, h)
@@ -253,12 +271,19 @@ def main():
     stats_all = gather_stats()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     kern_ms, launches = _native.kernel_ms_total(h, reset=True)
+    # spread of the launch time over the eight batch orders (outside the timed region: one launch each, HIP events)
+    order_ms = []
+    for k in range(NORD):
+        batches[k].solve(_native, h)
+        _native.synchronize(h)
+        ms_k, n_k = _native.kernel_ms_total(h, reset=True)
+        order_ms.append(ms_k / max(n_k, 1))
     stats_np = stats_all.cpu().numpy()
     status_all, iters_all = stats_np[:, 0], stats_np[:, 1]
 
@@ -268,6 +293,10 @@ def main():
         roof, dims, opt, inf = roofline_entry(_native, h, batch, None, avg_ms)
         bytes_solve = 8 * (2 * nx) + 8 * (N * nu + nx + nx + nu) + 8      # inputs + the outputs this call writes + status/iters
         roof["traffic"] = measured_traffic(roof["kernel"])
+        roof["traffic_source"] = TRAFFIC_PROFILE
+        roof["launch_ms_by_order"] = {"min": min(order_ms), "max": max(order_ms), "mean": float(np.mean(order_ms)),
+                                       "note": "one launch per batch order, same 4096 states (two instances per resident wave: the "
+                                               "launch ends with its slowest wave)"}
         roof["note"] = ("bound is FP64 arithmetic (vector ALU + the FP64 MFMA normal-matrix pass; 78.6 TFLOP/s is the peak of "
                         "either), not HBM: algorithmic HBM bytes are %d B/solve" % bytes_solve)
         roof["hbm"] = {"achieved": bytes_solve * B / (avg_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -299,6 +328,14 @@ def main():
             out["cpu_baseline"] = {"value": ns / tc, "unit": "solves/s", "cores": cores, "kind": "port",
                                    "sample": f"{ns} instances drawn from the same 4096 states, oracle/tmpc_oracle.c (IPM + refinement), "
                                              f"OpenMP over the batch, {tc:.2f} s wall, mean iters {oc['iters'].mean():.2f}"}
+            # the same solver on ONE host thread (what the reference's loop has: one solve at a time)
+            n1 = 8192
+            t1 = time.perf_counter()
+            o1 = orc.solve(Xc[:n1], Rc[:n1], nthreads=1)
+            t1 = time.perf_counter() - t1
+            out["cpu_baseline"]["single_thread"] = {"value": n1 / t1, "unit": "solves/s", "cores": 1, "kind": "port",
+                                                    "sample": f"the first {n1} of those instances, one thread, {t1:.2f} s wall, "
+                                                              f"mean iters {o1['iters'].mean():.2f}"}
             # the reference's Monte-Carlo loop body (results_linear_system.py:209-291) on the host cores: numpy state
             # machines around the same CPU solver, all trajectories of a time step solved together
             def cpu_packets(x_hat, r, gamma=None):
@@ -371,7 +408,7 @@ def main():
                                  "batch": len(dirs), "solved": int((lp["status"] == 0).sum()),
                                  "note": "support LPs over the terminal set, host buffers in and out (set-up stage, DESIGN.md 7a)"}
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -256,6 +256,124 @@ def kkt_certificate_fast(qp: dict, v: np.ndarray, act_tol: float = 1e-7):
     return kkt_certificate(qp, v, act_tol)
 
 
+def _minimiser_on_set(qp: dict, v: np.ndarray, active=None, act_tol: float = 1e-7):
+    """How far is the candidate `v` from THE minimiser, entry by entry?  Exact, not a residual norm.
+
+    With the active set W identified at `v` (rows with slack <= act_tol; or handed in), the minimiser v_W of the
+    equality-constrained QP  min 1/2 v'Pv + q'v  s.t.  A v = b, G_W v = h_W  is the solution of a LINEAR system;
+    it is computed here by the null-space method, which tolerates the dependent rows of a degenerate vertex:
+
+        C = [A; G_W],  c = [b; h_W],  v_p = v + C^+ (c - C v),  Z = null(C),
+        (Z'PZ) w = -Z'(P v_p + q),    v_W = v_p + Z w.
+
+    If v_W satisfies every other inequality and its multipliers on W (least-squares fit of C' mu = -(P v_W + q)) are
+    non-negative, v_W is the minimiser of the inequality-constrained QP as well (strictly convex: unique), and
+    `v_W - v` is the error of the candidate.  A residual-based certificate scales with |q| (1e6 for the cart-pole, whose
+    terminal weight is 10 P, TubeTrackingMPC.py:27) and lets a 1e-6 shift of u_0 through; this does not.
+
+    Returns dict(dv = v_W - v, du0 = max |dv| over the entries of u_0, certified = v_W passes the two checks and the
+    face minimiser is resolved to 1e-11, r_ineq, min_mu, r_stat of v_W, resolution)."""
+    P, q, A, b, G, h = (qp[k] for k in ("P", "q", "A", "b", "G", "h"))
+    L = qp["layout"]
+    if active is None:
+        slack = h - G @ v
+        active = np.flatnonzero(slack <= act_tol * np.maximum(1.0, np.abs(h)))
+    C = np.vstack([A, G[active]]) if A.size else G[active]
+    c = np.concatenate([b, h[active]]) if A.size else h[active]
+    n = len(v)
+    if C.shape[0]:
+        rs = np.maximum(np.linalg.norm(C, axis=1), 1e-300)            # unit rows: the rank decision is about directions
+        U, sv, Vt = np.linalg.svd(C / rs[:, None], full_matrices=True)
+        rank = int((sv > 1e-10 * sv[0]).sum())
+        Z = Vt[rank:].T
+        resid = (c - C @ v) / rs
+        v_p = v + Vt[:rank].T @ ((U[:, :rank].T @ resid) / sv[:rank])
+    else:
+        Z, v_p = np.eye(n), v.copy()
+    last = 0.0
+    v_w = v_p
+    if Z.shape[1]:
+        # Newton's step on the face is exact in exact arithmetic; |q| ~ 1e6 and cond(Z'PZ) ~ 1e5 leave 1e-9 .. 1e-8 of it
+        # in floating point, so the step is repeated on what is left (iterative refinement); `last` = what the final
+        # repetition still moved, the resolution of the distance returned
+        Hz = Z.T @ P @ Z
+        cho = np.linalg.cholesky(Hz)
+        for _ in range(4):
+            w = np.linalg.solve(cho.T, np.linalg.solve(cho, -Z.T @ (P @ v_w + q)))
+            v_w = v_w + Z @ w
+            last = float(np.max(np.abs(Z @ w)))
+    g = P @ v_w + q
+    if C.shape[0]:
+        mu = (U[:, :rank] @ ((Vt[:rank] @ -g) / sv[:rank])) / rs      # minimum-norm multipliers, same rank decision as Z
+        r_stat = float(np.max(np.abs(g + C.T @ mu)) / max(1.0, np.max(np.abs(q))))
+        mu_in = mu[A.shape[0]:] if A.size else mu
+        if len(mu_in) and mu_in.min() < 0.0:
+            # degenerate vertex: the minimum-norm fit may put a negative weight on a dependent row although a
+            # non-negative combination exists; ask for one
+            from scipy.optimize import lsq_linear
+            lb = np.r_[np.full(A.shape[0] if A.size else 0, -np.inf), np.zeros(len(active))]
+            cs = np.maximum(np.linalg.norm(C, axis=1), 1e-300)
+            res = lsq_linear(C.T / cs, -g, bounds=(lb, np.full(C.shape[0], np.inf)), method="bvls", tol=1e-15,
+                             max_iter=10 * C.shape[0] + 100)
+            mu2 = res.x / cs
+            if np.max(np.abs(g + C.T @ mu2)) <= 1e-7 * max(1.0, np.max(np.abs(q))):
+                mu = mu2
+                r_stat = float(np.max(np.abs(g + C.T @ mu)) / max(1.0, np.max(np.abs(q))))
+                mu_in = mu[A.shape[0]:] if A.size else mu
+        mu_scale = max(1.0, float(np.abs(mu_in).max())) if len(mu_in) else 1.0
+        min_mu = float(mu_in.min()) if len(mu_in) else 0.0
+    else:
+        r_stat, min_mu, mu_scale, mu_in = float(np.max(np.abs(g)) / max(1.0, np.max(np.abs(q)))), 0.0, 1.0, np.zeros(0)
+    # violation of the other rows as a DISTANCE (rows of the un-condensed QP are not normalised: those of Z (-) W reach
+    # norms of 1e3, and 1e-9 on such a row is 1e-12 in the variables)
+    r_ineq = float(max(0.0, np.max((G @ v_w - h) / np.maximum(1.0, np.linalg.norm(G, axis=1))))) if G.size else 0.0
+    dv = v_w - v
+    return dict(dv=dv, du0=float(np.max(np.abs(dv[L.u(0)]))), r_ineq=r_ineq, min_mu=min_mu, r_stat=r_stat, mu_in=mu_in,
+                resolution=last,
+                certified=bool(r_ineq <= 1e-9 and min_mu >= -1e-9 * mu_scale and r_stat <= 1e-7 and last <= 1e-11),
+                n_active=int(len(active)))
+
+
+def minimiser_distance(qp: dict, v: np.ndarray, active=None, act_tol: float = 1e-7, rounds: int = 8):
+    """`_minimiser_on_set` with the working set corrected when the one identified at `v` does not certify (a row within
+    act_tol of its bound that is not active at the minimiser, or the reverse): the row with the most negative multiplier
+    leaves, violated rows enter -- a textbook primal-dual active-set correction, a few rounds at most because `v` is
+    already close.  The returned distance refers to the certified minimiser; `certified` False means no working set
+    certified within `rounds`, and the distance says nothing."""
+    G, h, A = qp["G"], qp["h"], qp["A"]
+    if active is None:
+        active = np.flatnonzero(h - G @ v <= act_tol * np.maximum(1.0, np.abs(h)))
+    active = np.asarray(active, dtype=int)
+    rn = np.maximum(1.0, np.linalg.norm(G, axis=1))
+    slack0 = (h - G @ v) / rn
+    d = None
+    for _ in range(rounds):
+        d = _minimiser_on_set(qp, v, active)
+        if d["certified"]:
+            break
+        v_w = v + d["dv"]
+        # a working set whose rows cannot all sit on their bounds (nearly parallel facets of the 854-row initial-state set
+        # with different offsets: the dependent system is met in the least-squares sense only): the row that was furthest
+        # from its bound at `v` leaves
+        loose = np.abs(G[active] @ v_w - h[active]) / rn[active] > 1e-9
+        if loose.any():
+            cand = active[loose]
+            active = np.setdiff1d(active, [cand[int(np.argmax(slack0[cand]))]])
+            continue
+        viol = np.flatnonzero((G @ v_w - h) / np.maximum(1.0, np.linalg.norm(G, axis=1)) > 1e-9)
+        viol = np.setdiff1d(viol, active)
+        if len(viol):
+            active = np.union1d(active, viol)
+            continue
+        mu_in = d["mu_in"]
+        if len(mu_in) and mu_in.min() < 0.0:
+            active = np.delete(active, int(np.argmin(mu_in)))
+            continue
+        break
+    d["active"] = active
+    return d
+
+
 def lp_infeasible(qp: dict) -> bool:
     """True iff {A v = b, G v <= h} is empty according to HiGHS (scipy.optimize.linprog, the
     LP solver the reference itself uses, utils_polytope.py:19) -- the solver-independent

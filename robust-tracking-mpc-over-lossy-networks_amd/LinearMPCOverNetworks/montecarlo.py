@@ -30,13 +30,15 @@ def shard_bounds(n_items: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_statistics(local, n_total: int, rank: int, world: int, group=None):
+def gather_statistics(local, n_total: int, rank: int, world: int, group=None, force_collective: bool = False):
     """All-gather of a (n_local, k) tensor of per-trajectory statistics into the global
     (n_total, k) table, identical on every rank.  Backend-agnostic: `nccl` (= RCCL over xGMI) on
-    the GPUs, `gloo` in the CPU tests.  Shards of unequal size are padded to the largest."""
+    the GPUs, `gloo` in the CPU tests.  Shards of unequal size are padded to the largest.
+    force_collective: a one-rank run goes through the collective as well (needs an initialised process group;
+    the single-GPU rehearsal of the RCCL path)."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force_collective:
         return local
     sizes = [shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0] for r in range(world)]
     if local.shape[0] != sizes[rank]:
@@ -293,7 +295,7 @@ def plant_callable(plant):
 
 def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240301, rank: int = 0, world: int = 1,
              extended: bool = False, device=None, on_device: bool = False, plant=None, warm_start: bool = False,
-             timing: bool = False, device_rng: bool = False):
+             timing: bool = False, device_rng: bool = False, force_collective: bool = False):
     """The Monte-Carlo sweep of results_linear_system.py:147-301 (BASELINE config 4): len(p_loss) x n_mc
     trajectories of T steps, sharded over `world` ranks (one process per GPU, contiguous p_loss-balanced
     shards), every time step of a shard solved by one kernel launch, statistics all-gathered at the end.
@@ -331,5 +333,5 @@ def mc_sweep(mpc, model: dict, p_loss, n_mc: int, T: int, ref, seed: int = 20240
     local = torch.tensor(np.column_stack(cols), dtype=torch.float64)
     if device is not None:
         local = local.to(device)
-    table = gather_statistics(local, n_total, rank, world)
+    table = gather_statistics(local, n_total, rank, world, force_collective=force_collective)
     return table.cpu().numpy(), pi

@@ -425,7 +425,9 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
                                           xu_ss, x_nom, status, iters, h->stream));
             continue;
         }
-        {
+        if (tmpc::parks_in_lds(v.shape)) {
+            v.d.save = nullptr;
+        } else {
             // one save slot per resident wave (at most 8 per CU), sized for this variant's row sides
             const size_t rs = static_cast<size_t>(2 * v.shape.dp + v.shape.ds + 2 * v.shape.cp + v.shape.cs);
             const size_t need = static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(float);

@@ -23,6 +23,7 @@
 //     incrementally (G z += alpha G dz).
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <type_traits>
@@ -1119,13 +1120,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                 if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
                 try_tol *= 1e-2;
             }
-            if (st == TMPC_STATUS_MAX_ITER) {
-                // iteration cap: if the iterate still violates the constraints, call it infeasible
-                double viol = 0.0;
-                for (int r = tid; r < nc; r += BT) viol = fmax(viol, gz_[r] - h_[r]);
-                viol = block_reduce1<SH::BW, OpMax>(viol, red, wave, lane);
-                if (viol > 1e-6 * hn) st = TMPC_STATUS_INFEASIBLE;
-            }
+            // (iteration cap: the last iterate goes out under TMPC_STATUS_MAX_ITER, see tmpc_kernels.hip; INFEASIBLE needs the
+            // Farkas-type certificate)
         }
 
         // ---------------------------------------------------------------- outputs
@@ -1187,14 +1183,14 @@ hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int
                           double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
     constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
     static_assert(lds <= 160 * 1024, "block shape does not fit the 160 KiB LDS of a CU");
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64] = {};       // (the size is a compile-time constant here: setting it twice is harmless)
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id].load(std::memory_order_acquire)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_block_kernel<T>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
-        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id].store(true, std::memory_order_release);
     }
     int64_t blocks = B < ws_blocks ? B : ws_blocks;
     if (blocks < 1) blocks = 1;

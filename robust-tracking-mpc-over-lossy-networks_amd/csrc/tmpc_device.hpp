@@ -74,6 +74,7 @@ struct KernelShape {
 bool pick_config(int nv, int nd2, int nd1, int kc, int nc2, int nc1, KernelShape *shape);
 size_t lds_bytes(const KernelShape &shape, int grows);      // grows = 4 * nks rows of dense functionals staged in LDS
 const char *kernel_name(const KernelShape &shape);
+bool parks_in_lds(const KernelShape &shape);               // the hand-over iterate stays in LDS: no DeviceQP::save slot needed
 
 // Work counters of the wave kernel's persistent grid: every launch draws its instances from a fresh, zeroed device word of
 // a ring that is cleared in one piece when it has gone round -- no reset and no extra stream operation per launch.

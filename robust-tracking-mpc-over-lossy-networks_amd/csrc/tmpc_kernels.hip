@@ -33,6 +33,7 @@
 // Numerics are float64 throughout: cond(Hs) ~ 3e5 after scaling and the weights span 1e-1 .. 5e6 (R vs 10 P).
 #include <hip/hip_runtime.h>
 
+#include <mutex>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -50,9 +51,9 @@ using wv::WAVE;
 using wv::dpp_mov_d;
 using wv::fast_rcp;
 using wv::readlane_d;
-using wv::rows_backsub_lane;
-using wv::rows_factor;
-using wv::rows_forward;
+using wv::lanes_backsub_lane;
+using wv::lanes_factor;
+using wv::lanes_forward;
 using wv::vmax;
 using wv::vmax_abs;
 using wv::vmin;
@@ -193,6 +194,19 @@ struct WaveLds {
     static constexpr int HROW = SH::RS * WAVE;                                          // right-hand side h, [side][lane]
     static constexpr int VEC = 9 * SH::NV + 32;                                         // q, z, cost gradient, x_k, ref, scratch, dz_aff, dz, Psi-coordinates
     static constexpr int TOTAL = BIG + SUMS + CSUMS + PMAT + HROW + VEC;
+    // The iterate of the hand-over is parked where the refinement leaves the workspace idle: behind its own arrays in BIG and
+    // in the totals of the sweeps, which follow BIG directly.  One 32-bit word per row side and lane holds lambda in single
+    // precision (the dual residual of the continuation is that of the iterate to 6e-8), then mu.  The slacks are not
+    // parked: h - G z is the slack up to the primal residual of the hand-over, so a row well above that takes it (r_p = 0
+    // there) and a row on its bound takes mu / lambda (solve_kernel has the rule).  Shapes without that much idle LDS
+    // park (s, lambda) in HBM (DeviceQP::save, single precision).
+    static constexpr int PARK_WORDS = SH::RS * WAVE + 2;
+    static constexpr int IDLE_WORDS = 2 * ((BIG - POL) + SUMS + CSUMS + PMAT);
+#ifdef TMPC_PARK_HBM
+    static constexpr bool PARK_LDS = false;      // diagnostic builds: every shape parks in HBM
+#else
+    static constexpr bool PARK_LDS = IDLE_WORDS >= PARK_WORDS;
+#endif
     static_assert(RED >= 2 * SH::NDP, "(D, t) of the dense functionals share the transposition tile");
 };
 
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters,
-    const int32_t *__restrict__ ws_in, int32_t *__restrict__ ws_out, unsigned long long *__restrict__ next_item) {
+    const int32_t *ws_in, int32_t *ws_out, unsigned long long *__restrict__ next_item) {      // (ws_in may alias ws_out: the closed loop updates the records in place)
     using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
     using WL = WaveLds<SH>;
     constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, KT = SH::KT, WCAP = SH::WCAP, LDG = SH::LDG;
@@ -379,6 +393,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *vec = hw + WL::HROW;
     double *dtw = red;                // [NDP][2] (D, t) of the dense functionals during the MFMA pass of sweep A (the tile is idle then)
     double *Mf = red + WL::RED;       // [NV][NV + 1]  normal matrix, then its factor (behind the transposition tile, inside the refinement's idle workspace)
+    unsigned *park = reinterpret_cast<unsigned *>(red + WL::POL);   // [RS][64] parked (s, lambda), see WaveLds::PARK_LDS
     double *qv = vec;                 // [NV] linear term
     double *zv = vec + NV;            // [NV] current z (wave-uniform copy)
     double *cgv = vec + 2 * NV;       // [NV] cost gradient
@@ -568,6 +583,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 double s[RS], lam[RS], rs[RS];
                 double *rpw = hw;       // carried primal residual, [side][lane], in the region of h
                 int it0 = 0;
+                double mu_hand = 0.0;       // mu of the iterate that is handed over
                 if (resume_it >= 0) {
                     // the refinement did not certify its working set: on with the interior-point iteration from the iterate of
                     // the hand-over (z is still in LDS, (s, lambda) come back from the wave's save slot, r_p is formed anew)
@@ -576,15 +592,26 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     wave_lds_fence();
                     (void)raw_slacks(s);
                     h_valid = false;
+                    const double park_mu = WL::PARK_LDS ? *reinterpret_cast<const double *>(park + RS * WAVE) : 0.0;
+                    const double park_thr = 1e3 * try_tol * hn;        // (try_tol is a hundredth of the hand-over's by now)
 #pragma unroll
                     for (int i = 0; i < RS; ++i) {
                         const bool vl = valid(i);
                         const double raw = s[i];
-                        double sv = static_cast<double>(save[i * WAVE + lane]);
-                        const double lv = static_cast<double>(save[(RS + i) * WAVE + lane]);
-                        // the rounding of s must not come back as a primal residual s - (h - G z): where the parked slack is the
-                        // raw slack to single precision, the raw slack is the better copy
-                        if (raw > 0.0 && fabs(sv - raw) <= 2.5e-7 * sv) sv = raw;
+                        double sv, lv;
+                        if constexpr (WL::PARK_LDS) {
+                            // h - G z is the slack up to the primal residual of the hand-over (<= tol hn): above ten times that
+                            // it IS the slack; below, the row sits on its bound as far as h - G z can tell and takes the
+                            // central path's mu / lambda, kept inside that band
+                            lv = fmax(static_cast<double>(__uint_as_float(park[i * WAVE + lane])), 1e-30);
+                            sv = raw > park_thr ? raw : fmin(fmax(raw, park_mu * fast_rcp(lv)), park_thr);
+                        } else {
+                            sv = static_cast<double>(save[i * WAVE + lane]);
+                            lv = static_cast<double>(save[(RS + i) * WAVE + lane]);
+                            // the rounding of s must not come back as a primal residual s - (h - G z): where the parked slack is
+                            // the raw slack to single precision, the raw slack is the better copy
+                            if (raw > 0.0 && fabs(sv - raw) <= 2.5e-7 * sv) sv = raw;
+                        }
                         s[i] = vl ? sv : 1.0;
                         lam[i] = vl ? lv : 0.0;
                         rpw[i * WAVE + lane] = vl ? sv - raw : 0.0;
@@ -717,7 +744,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             gn = fmax(gn, fabs(glj));
                         }
                         if (!(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
-                        if (near && rdn <= 1e3 * try_tol * qn) { want_polish = true; rdn_last = readlane_d(rdn, 0); break; }
+#ifdef TMPC_DEBUG_PRINT
+                        if (lane == 0 && b < 2) printf("b %lld it %d rdn %.3e qn %.3e\n", (long long)b, it, rdn, qn);
+#endif
+                        if (near && rdn <= 1e3 * try_tol * qn) { want_polish = true; rdn_last = readlane_d(rdn, 0); mu_hand = readlane_d(mu, 0); break; }
                         if (lmax > 1e10) {
                             // Farkas-type certificate: lam blows up, G'lam -> 0, h'lam < 0
                             double hl = 0.0;       // (h is formed on the fly: its LDS region holds r_p here)
@@ -732,6 +762,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             if (hl < 0.0 && gn <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
                         }
                     }
+#ifdef TMPC_DEBUG_PRINT
+                    if (lane == 0 && b < 2) printf("b %lld it %d gap %.3e objs %.3e rpn %.3e hn %.3e lmax %.3e near %d tol %.1e\n", (long long)b, it, gap, objs, rpn, hn, lmax, (int)near, try_tol);
+#endif
                     if (gap <= 1e-15 * objs) { st = TMPC_STATUS_MAX_ITER; break; }
                     // ---- M = Hs + G'DG by rows (lane i holds row i), elimination with the predictor rhs carried along
                     TMPC_REFRESH();
@@ -765,14 +798,14 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             }
                             wave_lds_fence();
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) mrow[j] = (lane < NV) ? mt[j] : 0.0;
+                            for (int j = 0; j < NV; ++j) mrow[j] = mt[j];      // (lanes >= NV eliminate a copy of row 0 that nothing reads)
                             wave_lds_fence();
                             rhs_i = (lane < NV) ? -cgv[li] - sums[li] : 0.0;
                             double bb = rhs_i;
                             mdinv = 1.0;
-                            spd = rows_factor<NV>(mrow, bb, mdinv, lane);
+                            spd = lanes_factor<NV>(mrow, bb, mdinv, lane);
                             if (spd) {
-                                const double xl = rows_backsub_lane<NV>(mrow, bb, mdinv, lane);
+                                const double xl = lanes_backsub_lane<NV>(mrow, bb, mdinv, lane);
                                 if (lane < NV) {
                                     dzav[lane] = xl;
                                     // the factor waits in LDS for the corrector's solve: 2 NV registers less through sweep B
@@ -882,8 +915,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         for (int j = 0; j < NV; ++j) mrow[j] = Mf[li * (NV + 1) + j];
                         const double mdinv = Mf[li * (NV + 1) + NV];
                         double bb = (lane < NV) ? rhs_i + v2 - smu * v3 : 0.0;
-                        rows_forward<NV>(mrow, bb, lane);
-                        const double xl = rows_backsub_lane<NV>(mrow, bb, mdinv, lane);
+                        lanes_forward<NV>(mrow, bb, lane);
+                        const double xl = lanes_backsub_lane<NV>(mrow, bb, mdinv, lane);
                         if (lane < NV) dzv[lane] = xl;
                     }
                     wave_lds_fence();
@@ -937,6 +970,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                 }
                 // hand-over: the working set and its multipliers are all the refinement takes from (s, lambda)
                 TMPC_REFRESH();
+#ifdef TMPC_DEBUG_PRINT
+                if (lane == 0 && b < 2) printf("b %lld ipm exit: it_done %d st %d want_polish %d tol %.1e it0 %d\n", (long long)b, it_done, st, (int)want_polish, try_tol, it0);
+#endif
 #pragma unroll
                 for (int i = 0; i < RS; ++i) { inW[i] = valid(i) && (lam[i] > s[i]); yall[i] = lam[i]; }
 #ifdef TMPC_ITERS_TOTAL
@@ -954,7 +990,16 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     amb_level = -static_cast<int>(wave_max(-static_cast<double>(amb_level)));
                 }
 #endif
-                if (save != nullptr && want_polish) {
+                if constexpr (WL::PARK_LDS) {
+                    // parked in LDS: every hand-over, a store per row side (WaveLds::PARK_LDS has the form of the continuation)
+                    if (want_polish) {
+#pragma unroll
+                        for (int i = 0; i < RS; ++i) park[i * WAVE + lane] = __float_as_uint(static_cast<float>(lam[i]));
+                        if (lane == 0) *reinterpret_cast<double *>(park + RS * WAVE) = mu_hand;
+                        saved = true;
+                        wave_lds_fence();
+                    }
+                } else if (save != nullptr && want_polish) {
                     // (s, lambda) are parked only when they do not separate the working set clearly -- some row with lambda / s
                     // within two decades of 1: every re-run but 3 of 30 720 closed-loop instances at N = 10 (13 at N = 20) comes
                     // from that fifth of the instances -- and in single precision: the continuation starts from an interior point
@@ -1096,7 +1141,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         }
                         {
                             double bdummy = 0.0;
-                            if (!rows_factor<MC>(srow, bdummy, sdinv, lane)) return false;
+                            if (!lanes_factor<MC>(srow, bdummy, sdinv, lane)) return false;
                         }
                         STAMP(12);
                         // proximal Newton steps on the KKT system of the working set (at most twelve -- nearly parallel working rows need them --; they stop once a step
@@ -1129,8 +1174,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 for (int j = 0; j < NV; ++j) { const double g = GW[lane * NV + j]; gz += g * zpv[j]; gt += g * uv[j]; }
                                 bb = gz - hw[Widx[lane]] - gt;
                             }
-                            rows_forward<MC>(srow, bb, lane);
-                            const double dyl = rows_backsub_lane<MC>(srow, bb, sdinv, lane);
+                            lanes_forward<MC>(srow, bb, lane);
+                            const double dyl = lanes_backsub_lane<MC>(srow, bb, sdinv, lane);
                             if (lane < m) { dyv[lane] = dyl; yv[lane] += dyl; }
                             wave_lds_fence();
                             // zp -= t1 + T dy  (lane j -> entry j)
@@ -1250,15 +1295,13 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             ++n_reruns;
 #endif
         }
-        if (st == TMPC_STATUS_MAX_ITER) {
-            // iteration cap: if the iterate still violates the constraints, call it infeasible
-            if (!h_valid) { compute_h(); h_valid = true; }
-            coords_lds<SH>(Psi, zv, czv, lane);
-            wave_lds_fence();
-            double sl[RS];
-            const double smin = wave_min(raw_slacks(sl));
-            if (-smin > 1e-6 * hn) st = TMPC_STATUS_INFEASIBLE;
-        }
+        // (iteration cap or a stalled gap: the last iterate goes out under TMPC_STATUS_MAX_ITER -- the reference uses what an
+        // inaccurate solve leaves in its variables, TubeTrackingMPC.py:185-192; INFEASIBLE is only ever declared with the
+        // Farkas-type certificate of the interior-point phase or by the rows that depend on x_k alone)
+#ifdef TMPC_DEBUG_PRINT
+        if (lane == 0 && (st == TMPC_STATUS_MAX_ITER || st == TMPC_STATUS_NUMERICAL) && nx == 4)
+            printf("NONOPT b %lld st %d it %d tol %.1e x %a %a %a %a r %a\n", (long long)b, st, it_done, try_tol, xin[0], xin[1], xin[2], xin[3], xin[4]);
+#endif
         if (ws_out != nullptr && lane == 0) ws_out[b * WS_STRIDE] = ws_m;
 
         // ---------------------------------------------------------------- outputs
@@ -1351,15 +1394,21 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     const size_t lds = kernel_lds_bytes<SH>(WPB, 4 * qp.nks);
     if (lds > 160 * 1024) return hipErrorInvalidValue;       // (tmpc_api.cpp checks lds_bytes() before it accepts the wave path)
     static_assert(SH::RS <= 32, "validity mask is one 32-bit word per lane");
-    // > 64 KiB of dynamic LDS needs the opt-in once per device and instantiation
-    static bool attr_set[64] = {};
-    int dev_id = 0;
-    (void)hipGetDevice(&dev_id);
-    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, DP, DS, KC, CP, CS, WPB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+    // > 64 KiB of dynamic LDS needs the opt-in per device and instantiation.  The size depends on the problem (rows of dense
+    // functionals staged), so the attribute is raised whenever a handle asks for more than any before it on this device
+    // (handles may be driven from different host threads: the check and the call are one critical section).
+    {
+        static std::mutex attr_mutex;
+        static size_t attr_lds[64] = {};
+        int dev_id = 0;
+        (void)hipGetDevice(&dev_id);
+        std::lock_guard<std::mutex> guard(attr_mutex);
+        if (dev_id < 0 || dev_id >= 64 || attr_lds[dev_id] < lds) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, DP, DS, KC, CP, CS, WPB>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+            if (dev_id >= 0 && dev_id < 64) attr_lds[dev_id] = lds;
+        }
     }
     int64_t blocks = (B + WPB - 1) / WPB;
     // one persistent workgroup per CU (the LDS footprint admits no second one): the model is staged once and every wave
@@ -1403,6 +1452,15 @@ size_t lds_bytes(const KernelShape &s, int grows) {
     TMPC_SHAPES(TMPC_LDS)
 #undef TMPC_LDS
     return 0;
+}
+
+bool parks_in_lds(const KernelShape &s) {
+#define TMPC_PARK(A, B_, C, D, E, F) \
+    if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F) \
+        return WaveLds<Shape<A, B_, C, D, E, F, tile_rows(A, waves_per_block<A, B_, C, D, E, F>())>>::PARK_LDS;
+    TMPC_SHAPES(TMPC_PARK)
+#undef TMPC_PARK
+    return false;
 }
 
 const char *kernel_name(const KernelShape &s) {

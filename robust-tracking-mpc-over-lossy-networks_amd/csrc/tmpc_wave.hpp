@@ -3,6 +3,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <utility>
+
 namespace tmpc {
 namespace wv {
 
@@ -127,6 +129,84 @@ __device__ __forceinline__ double rows_backsub_lane(const double (&row)[N], doub
         b = fma(-row[i], xi, b);
     }
     return xl;
+}
+
+// ---- the same three routines for N <= 16 with the pivot row handed round by ONE 64-bit DPP move instead of two
+// v_readlane_b32: `v_mov_b64_dpp ... row_newbcast:k` (gfx90a and later; the only DPP control the double-precision ALU
+// takes) copies lane k of every 16-lane row to the whole row.  Two instructions per multiply-add of the elimination
+// instead of three, and no SGPR round trip.  Every 16-lane row of the wave works on the matrix whose row i sits on its
+// lane i: the callers keep theirs on lanes 0 .. N-1 and ignore what the other three rows compute.
+template <int K>
+__device__ __forceinline__ double row_bcast_d(double v) {
+    return __builtin_amdgcn_mov_dpp(v, 0x150 + K, 0xF, 0xF, false);      // row_newbcast:K
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for_n(F &&f) {
+    [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
+}
+// returns whether the matrix of lanes 0 .. N-1 had positive pivots (wave-uniform)
+template <int N>
+__device__ __forceinline__ bool rows16_factor(double (&row)[N], double &b, double &dinv, int lane) {
+    static_assert(N <= 16, "one matrix row per lane of a 16-lane DPP row");
+    const int l16 = lane & 15;
+    bool ok = true;
+    static_for_n<N>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        const double pkk = row_bcast_d<k>(row[k]);
+        ok = ok && (pkk > 0.0);
+        const double pinv = fast_rcp(pkk);
+        const double f = (l16 > k) ? row[k] * pinv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) row[j] = fma(-f, row_bcast_d<k>(row[j]), row[j]);
+        b = fma(-f, row_bcast_d<k>(b), b);
+        if (l16 > k) row[k] = f;
+        if (l16 == k) dinv = pinv;
+    });
+    return __builtin_amdgcn_readfirstlane(static_cast<int>(ok)) != 0;
+}
+template <int N>
+__device__ __forceinline__ void rows16_forward(const double (&row)[N], double &b, int lane) {
+    const int l16 = lane & 15;
+    static_for_n<N - 1>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        const double f = (l16 > k) ? row[k] : 0.0;
+        b = fma(-f, row_bcast_d<k>(b), b);
+    });
+}
+template <int N>
+__device__ __forceinline__ double rows16_backsub_lane(const double (&row)[N], double b, double dinv, int lane) {
+    const int l16 = lane & 15;
+    double xl = 0.0;
+    static_for_n<N>([&](auto r_) {
+        constexpr int i = N - 1 - decltype(r_)::value;
+        const double bi = b * dinv;
+        const double xi = row_bcast_d<i>(bi);
+        xl = (l16 == i) ? bi : xl;
+        b = fma(-row[i], xi, b);
+    });
+    return xl;
+}
+// dispatch: the DPP form where a matrix fits a 16-lane row, the readlane form otherwise (-DTMPC_NO_DPP64: diagnostic
+// builds with the readlane form throughout)
+#ifdef TMPC_NO_DPP64
+constexpr int DPP_ROW = 0;
+#else
+constexpr int DPP_ROW = 16;
+#endif
+template <int N>
+__device__ __forceinline__ bool lanes_factor(double (&row)[N], double &b, double &dinv, int lane) {
+    if constexpr (N <= DPP_ROW) return rows16_factor<N>(row, b, dinv, lane);
+    else return rows_factor<N>(row, b, dinv, lane);
+}
+template <int N>
+__device__ __forceinline__ void lanes_forward(const double (&row)[N], double &b, int lane) {
+    if constexpr (N <= DPP_ROW) rows16_forward<N>(row, b, lane);
+    else rows_forward<N>(row, b, lane);
+}
+template <int N>
+__device__ __forceinline__ double lanes_backsub_lane(const double (&row)[N], double b, double dinv, int lane) {
+    if constexpr (N <= DPP_ROW) return rows16_backsub_lane<N>(row, b, dinv, lane);
+    else return rows_backsub_lane<N>(row, b, dinv, lane);
 }
 
 }  // namespace wv

@@ -1,5 +1,5 @@
 """Generates tests/golden/glue_golden.npz by RUNNING THE REFERENCE's numpy-only classes
-(`Estimator`, `RobustEstimator`, `ConsistentActuator` from /root/reference/src, importable in the
+(`Estimator`, `RobustEstimator`, `ConsistentActuator`, `SmartActuator` from /root/reference/src, importable in the
 build container; they need neither cvxpy nor polytope) on scripted packet-loss patterns with
 synthetic controller packets.  Only inputs and the recorded outputs are stored; no reference code
 travels.  The batched state machines in LinearMPCOverNetworks/{Estimator,SmartActuator}.py must
@@ -57,6 +57,33 @@ def run(extended, p_loss, seed):
     return {k: np.array(v) for k, v in rec.items()}
 
 
+def run_smart(p_loss, seed):
+    """The comparator's loop (results_linear_system.py:198-205, :262-287): the reference's plain `SmartActuator`
+    (SmartActuator.py:11-123) with its `Estimator`; the MPC's packets are synthetic, everything else is the reference's code."""
+    rng = np.random.default_rng(1000 + seed)
+    x0 = np.zeros((nx, 1))
+    est = RefEst.Estimator(A, B, K, x0.copy(), N)
+    act = RefAct.SmartActuator(K)
+    x = x0.copy()
+    rec = {k: [] for k in ("U", "theta", "gamma", "wv", "q", "u", "x", "xhat", "s", "Theta", "pkt_x")}
+    for t in range(T):
+        theta = 1 if t == 0 else int(rng.uniform() >= p_loss)
+        gamma = 1 if t == 0 else int(rng.uniform() >= p_loss)
+        wv = rng.uniform(-1, 1, (nx, 1)) * w["w_bound"].reshape(nx, 1)
+        q = est.get_qt()
+        U = 0.3 * rng.normal(size=(nu, N + 1))
+        est.store_sent_control_sequence(U.copy())
+        u, ppkt = act.process_packet({"U_t": U.copy(), "q_t": q}, x.copy(), theta)
+        rec["pkt_x"].append(np.array(ppkt["x_t"]).reshape(nx).copy())
+        x = A @ x + B @ u + wv
+        est.update_estimate({k: (np.array(v).copy() if isinstance(v, np.ndarray) else v) for k, v in ppkt.items()}, gamma)
+        for k, v in (("U", U), ("theta", theta), ("gamma", gamma), ("wv", wv.reshape(nx)), ("q", q), ("u", np.array(u).reshape(nu)),
+                     ("x", x.reshape(nx)), ("xhat", np.array(est.get_estimate()).reshape(nx)), ("s", act.get_s_t()),
+                     ("Theta", act.get_Theta_t())):
+            rec[k].append(np.array(v).copy())
+    return {k: np.array(v) for k, v in rec.items()}
+
+
 if __name__ == "__main__":
     out = {"A": A, "B": B, "K": K, "Kp": Kp, "N": N}
     cases = []
@@ -70,3 +97,15 @@ if __name__ == "__main__":
     out["cases"] = np.array(cases)
     np.savez_compressed(os.path.join(HERE, "glue_golden.npz"), **out)
     print(len(cases), "cases written")
+    # the plain smart actuator of the non-robust comparator, its own file (glue_golden.npz stays as recorded in round 1)
+    smart = {"A": A, "B": B, "K": K, "N": N, "w_bound": w["w_bound"]}
+    scases = []
+    for p in (0.0, 0.3, 0.6, 0.9):
+        for seed in (1, 2, 3):
+            name = f"sa_p{int(p * 10)}_s{seed}"
+            scases.append(name)
+            for k, v in run_smart(p, seed).items():
+                smart[f"{name}/{k}"] = v
+    smart["cases"] = np.array(scases)
+    np.savez_compressed(os.path.join(HERE, "glue_smart_golden.npz"), **smart)
+    print(len(scases), "smart-actuator cases written")

@@ -191,3 +191,40 @@ def test_extended_variant_with_auxiliaries_eliminated(oracle_lib):
         res = linprog(np.zeros(3), A_ub=np.c_[HT[:, :2], HT[:, 4:]], b_ub=hT - HT[:, 2:4] @ a["x_ss"][i] + 1e-9,
                       bounds=(None, None), method="highs")
         assert res.status == 0
+
+
+def test_minimiser_distance_measures_u0_shift():
+    """qp_sparse.minimiser_distance is the entry-wise distance to the exact minimiser on the certified active set.  The
+    residual-based KKT certificate normalises by |q| (1e6 for the cart-pole, T = 10 P) and lets a 1e-6 shift of u_0 through
+    (instance 123 of the fixture: r_stat 5.7e-9 < 1e-7); the distance reads 1.0e-6 for that very point."""
+    import os
+    import common
+    from oracle import qp_sparse
+    from oracle.oracle import Oracle
+    S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
+    mpc, _ = common.make_mpc("cartpole", 10, True, create=False)
+    p = mpc._problem_dict()
+    idx = np.r_[123, np.arange(0, 600, 12)]
+    out = Oracle(p).solve(S[idx, :4], S[idx, 4:])
+    tpl = qp_sparse.SparseTemplate(p, 0)
+    A, B = np.asarray(p["A"]), np.asarray(p["B"])
+    worst = 0.0
+    for j, k in enumerate(idx):
+        assert out["status"][j] == 0
+        qp = tpl.instance(S[k, :4], S[k, 4:])
+        v = qp_sparse.pack(qp, out["x_nom"][j], out["u_nom"][j], out["x_ss"][j], out["u_ss"][j])
+        d = qp_sparse.minimiser_distance(qp, v)
+        assert d["certified"] and d["du0"] < 1e-9, (k, d["du0"], d["certified"])
+        worst = max(worst, d["du0"])
+    # the probe: u_0 moved by 1e-6, trajectory re-simulated (equalities hold), everything else as returned
+    qp = tpl.instance(S[123, :4], S[123, 4:])
+    u = out["u_nom"][0].copy()
+    u[0] += 1e-6
+    x = [S[123, :4]]
+    for i in range(10):
+        x.append(A @ x[-1] + B @ u[i])
+    v2 = qp_sparse.pack(qp, np.array(x), u, out["x_ss"][0], out["u_ss"][0])
+    c2 = qp_sparse.kkt_certificate_fast(qp, v2)
+    d2 = qp_sparse.minimiser_distance(qp, v2)
+    assert c2["r_stat"] < 1e-7                    # the residual certificate does not see it
+    assert d2["certified"] and abs(d2["du0"] - 1e-6) < 1e-8, d2["du0"]      # the distance does
