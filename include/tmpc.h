@@ -18,6 +18,7 @@
 #ifndef TMPC_H
 #define TMPC_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -180,6 +181,15 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant);
  * workgroup) or "tmpc::solve_block_kernel<T>" (one workgroup per QP).  The string belongs to the library.
  */
 const char *tmpc_kernel_name(const tmpc_handle *h, int variant);
+
+/*
+ * Diagnostics (tests/wavesim: the kernel sources compiled for the CPU under sanitizers): a copy of the structure the
+ * wave-per-QP kernel receives for `variant` (tmpc::DeviceQP of csrc/tmpc_device.hpp, `wave_qp_bytes` must be its size),
+ * its compiled shape (NVP, DP, DS, KC, CP, CS) and whether a shape covers the variant.  For a host-only handle
+ * (device < 0) every pointer in the copy is a HOST pointer owned by the handle; for a device handle they are device
+ * pointers.  Not part of the solve path.
+ */
+int tmpc_debug_layout(const tmpc_handle *h, int variant, void *wave_qp, size_t wave_qp_bytes, int32_t shape[6], int *wave_ok);
 
 /*
  * Device-resident closed loop over a lossy network for B independent trajectories and T time steps: the body

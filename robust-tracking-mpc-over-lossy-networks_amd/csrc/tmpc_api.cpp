@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -97,6 +98,16 @@ namespace {
 template <class T>
 int upload(tmpc_handle *h, Variant &v, const T *src, size_t n, const T **dst) {
     void *p = nullptr;
+    if (h->device < 0) {
+        // host-only handle: the layouts the kernels read are kept in host memory (tmpc_debug_layout; tests/wavesim runs
+        // the kernel sources on the CPU against them)
+        p = std::malloc((n ? n : 1) * sizeof(T));
+        if (!p) { h->err = "out of memory"; return TMPC_E_NOMEM; }
+        v.dev.push_back(p);
+        if (n) std::memcpy(p, src, n * sizeof(T));
+        *dst = static_cast<const T *>(p);
+        return TMPC_OK;
+    }
     HIP_TRY(h, hipMalloc(&p, (n ? n : 1) * sizeof(T)));
     v.dev.push_back(p);
     if (n) HIP_TRY(h, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
@@ -533,6 +544,9 @@ int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
                 rc = setup();
             }
         }
+        if (rc == TMPC_OK && device < 0) {
+            for (int k = 0; k < h->nvariants && rc == TMPC_OK; ++k) rc = upload_variant(h, h->v[k], *p);
+        }
     } catch (const std::exception &ex) {
         h->err = std::string("tmpc_create: ") + ex.what();
         rc = TMPC_E_NOMEM;
@@ -548,7 +562,12 @@ int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
 
 void tmpc_destroy(tmpc_handle *h) {
     if (!h) return;
-    if (h->device < 0) { delete h; return; }
+    if (h->device < 0) {
+        for (int k = 0; k < 2; ++k)
+            for (void *p : h->v[k].dev) std::free(p);
+        delete h;
+        return;
+    }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     free_staging(h);
@@ -615,8 +634,19 @@ int tmpc_set_kernel_path(tmpc_handle *h, int path) {
 
 int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
     if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
-    if (h->device < 0) return TMPC_PATH_AUTO;
-    return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;
+    return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;       // (host-only handles included: the choice is made at tmpc_create)
+}
+
+int tmpc_debug_layout(const tmpc_handle *h, int variant, void *wave_qp, size_t wave_qp_bytes, int32_t shape[6], int *wave_ok) {
+    if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    const Variant &v = h->v[variant];
+    if (wave_qp) {
+        if (wave_qp_bytes != sizeof(tmpc::DeviceQP)) return TMPC_E_INVALID;
+        std::memcpy(wave_qp, &v.d, sizeof(tmpc::DeviceQP));
+    }
+    if (shape) { shape[0] = v.shape.nvp; shape[1] = v.shape.dp; shape[2] = v.shape.ds; shape[3] = v.shape.kcp; shape[4] = v.shape.cp; shape[5] = v.shape.cs; }
+    if (wave_ok) *wave_ok = v.wave_ok ? 1 : 0;
+    return TMPC_OK;
 }
 
 const char *tmpc_kernel_name(const tmpc_handle *h, int variant) {

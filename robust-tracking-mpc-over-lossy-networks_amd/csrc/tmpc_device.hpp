@@ -1,7 +1,11 @@
 // Device-side view of one condensed, scaled QP variant and the launch interface
 // between tmpc_api.cpp (host) and tmpc_kernels.hip (device).
 #pragma once
+#ifdef TMPC_HOST_SIM
+#include "hip_sim.hpp"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cstddef>
 #include <cstdint>

@@ -31,10 +31,14 @@
 // have been reduced to the working set, so the two phases never hold registers at the same time.
 //
 // Numerics are float64 throughout: cond(Hs) ~ 3e5 after scaling and the weights span 1e-1 .. 5e6 (R vs 10 P).
+#ifdef TMPC_HOST_SIM
+#include "hip_sim.hpp"      // tests/wavesim: this very source compiled for the CPU under sanitizers (never in the product)
+#else
 #include <hip/hip_runtime.h>
+#endif
 
-#include <mutex>
 #include <cmath>
+#include <mutex>
 #include <cstdint>
 #include <string>
 #include <type_traits>
@@ -61,9 +65,16 @@ using wv::OpMax;
 using wv::OpMin;
 using wv::OpSum;
 
+#ifdef TMPC_HOST_SIM
+unsigned long sim_rendezvous_total = 0;
+#endif
 constexpr int RED_STRIDE = 68;      // 64 lanes + a pad after every 16: conflict-free transposed reads
+constexpr int ZERO_ROWS = 4;        // zero rows behind the staged dense functionals: row `grows` stands for every functional beyond them,
+                                    // and the look-ahead of the MFMA pass ends one k-step (four rows) past the last one it multiplies
 
-#ifdef TMPC_STAMPS
+#if defined(TMPC_HOST_SIM)
+#define STAMP(p) do { } while (0)
+#elif defined(TMPC_STAMPS)
 #define STAMP(p) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); long long now_ = __builtin_amdgcn_s_memtime(); \
                       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tph[p] += now_ - tlast; tlast = now_; } while (0)
 #else
@@ -72,12 +83,17 @@ constexpr int RED_STRIDE = 68;      // 64 lanes + a pad after every 16: conflict
 
 // Compiler-only barrier between two slots of a sweep: without it the loads of ALL slots are hoisted to the top of the
 // unrolled loop and the kernel spills to scratch.
+#ifdef TMPC_HOST_SIM
+__device__ __forceinline__ void row_fence() {}        // (scheduling only: no LDS hand-over depends on it)
+__device__ __forceinline__ void wave_lds_fence() { sim::wave_fence(); }
+#else
 __device__ __forceinline__ void row_fence() {
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }
 // Orders one wave's LDS traffic for the compiler (the hardware runs the DS instructions of a wave in issue order).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("" ::: "memory"); }
+#endif
 
 // 1/x to ~2^-27 for x > 0: v_rcp_f64 (good to about 2^-14) + ONE Newton step.  Used where the reciprocal only ranks
 // step-length ratios against a fraction-to-the-boundary margin of at least 1e-4; the slacks' reciprocals, which enter the
@@ -96,7 +112,11 @@ __device__ __forceinline__ double wave_max(double v) { return wv::wave_reduce<Op
 // where it then has to survive the whole solve: hundreds of SGPR pairs parked in VGPR lanes and 64-bit addresses in
 // scratch.  Re-deriving them from a fresh copy at every phase boundary costs an instruction each and keeps them local.
 __device__ __forceinline__ int fresh(int v) {
+#ifdef TMPC_HOST_SIM
+    asm volatile("" : "+r"(v));
+#else
     asm volatile("" : "+v"(v));
+#endif
     return v;
 }
 
@@ -120,9 +140,11 @@ __device__ __forceinline__ void wave_reduce_to_lds(const double (&acc)[CNT], dou
         for (int k = 0; k < RR; ++k)
             if (c0 + k < CNT) red[k * RED_STRIDE + wcol] = acc[c0 + k];
         wave_lds_fence();
-        double t = 0.0;
+        // (four partial sums: a chain of four dependent additions instead of sixteen)
+        double t4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 16; ++j) t += red[er * RED_STRIDE + qd * 17 + j];
+        for (int j = 0; j < 16; ++j) t4[j & 3] += red[er * RED_STRIDE + qd * 17 + j];
+        double t = (t4[0] + t4[1]) + (t4[2] + t4[3]);
         t += dpp_mov_d<0xB1>(t);
         t += dpp_mov_d<0x4E>(t);
         if (qd == 0 && e < RR && c0 + e < CNT) out[c0 + e] = t;
@@ -156,6 +178,10 @@ struct Shape {
     static constexpr int RS = 2 * DP_ + DS_ + 2 * CP_ + CS_;      // row sides per lane
     static constexpr int NT = NV_ * (NV_ + 1) / 2, KT = KC_ * (KC_ + 1) / 2;
     static constexpr int WCAP = NV_ <= 24 ? 24 : 28;              // max rows in the refinement's working set (<= WS_CAP)
+    // row strides of the small LDS matrices that are read with the row on the lane (Hs, Hs^-1, the expanded working rows;
+    // T = Hs^-1 G_W'): odd, so that the lanes' rows start in different banks (NV = 24 unpadded: six rows per bank)
+    // (not for NV = 28: that shape's four workspaces fill the LDS to the last kilobyte)
+    static constexpr int LDH = NV_ + (NV_ <= 24 ? 1 : 0), LDT = WCAP + (NV_ <= 24 ? 1 : 0);
     // dense functionals, row-major in LDS: [FD * 64][LDG]; 16-column blocks of the MFMA tiling cover the NV columns of G
     // plus one more row of the product (row NV of A carries t: see sweep_a_dense); the odd stride keeps both the
     // lane-per-row reads of the sweeps and the 4 x 16 operand reads of the MFMA loop conflict free
@@ -185,7 +211,7 @@ __device__ __forceinline__ void side_info(int i, bool &dense, int &fslot, double
 template <class SH>
 struct WaveLds {
     static constexpr int RED = SH::RR * RED_STRIDE;                                     // transposition tile
-    static constexpr int POL = 2 * SH::NV * SH::WCAP + 4 * SH::WCAP;                            // G_W, T, y, dy, W(idx)
+    static constexpr int POL = SH::WCAP * SH::LDH + SH::NV * SH::LDT + 4 * SH::WCAP;              // G_W, T, y, dy, W(idx)
     static constexpr int MFAC = SH::NV * (SH::NV + 1);                                  // factor of the normal matrix between the two solves (row i at i (NV + 1), then 1 / d_i)
     static constexpr int BIG = RED + MFAC > POL ? RED + MFAC : POL;                     // tile + factor (interior point) and the refinement's workspace are never live together
     static constexpr int SUMS = 2 * SH::NV + 8;                                         // two NV-vectors of G' products
@@ -278,26 +304,51 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, int nks, const d
     wave_lds_fence();
     const int c = lane & 15, kq = lane >> 4;
     const double tmask = (c == CT) ? 1.0 : 0.0;
-    v4d acc[SH::NTL];
+    // Two k-steps in flight: the operands of step ks + 1 are on their way while step ks multiplies (an LDS round trip per
+    // step otherwise), and with a single tile (NB = 1) even and odd steps accumulate into tiles of their own, so that
+    // successive matrix instructions do not wait for each other's result.
+    constexpr int NACC = SH::NTL == 1 ? 2 : 1;
+    v4d acc[NACC][SH::NTL];
 #pragma unroll
-    for (int q = 0; q < SH::NTL; ++q) acc[q] = v4d{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-    for (int ks = 0; ks < nks; ++ks) {
-        const int f = 4 * ks + kq;
-        const double Dk = dtw[2 * f], tk = dtw[2 * f + 1];
-        double g[NB], a[NB];
+    for (int h2 = 0; h2 < NACC; ++h2)
 #pragma unroll
-        for (int blk = 0; blk < NB; ++blk) {
-            g[blk] = Gt[f * LDG + 16 * blk + c];
-            a[blk] = Dk * g[blk];
-        }
+        for (int q = 0; q < SH::NTL; ++q) acc[h2][q] = v4d{0.0, 0.0, 0.0, 0.0};
+    // (k-step ks reads functional 4 ks + kq; the look-ahead fetches k-step nks at most: ZERO_ROWS)
+    const double *dp = dtw + 2 * kq, *gp = Gt + kq * LDG + c;
+    auto fetch = [&](double &Dk, double &tk, double (&g)[NB]) {
+        Dk = dp[0];
+        tk = dp[1];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) g[blk] = gp[16 * blk];
+        dp += 8;
+        gp += 4 * LDG;
+    };
+    auto multiply = [&](auto h_, double Dk, double tk, const double (&g)[NB]) {
+        constexpr int h2 = decltype(h_)::value;
+        double a[NB];
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) a[blk] = Dk * g[blk];
         a[IT] = fma(tmask, tk, a[IT]);              // (column NV of G is zero: row NV of the product is G't)
 #pragma unroll
         for (int I = 0; I < NB; ++I)
 #pragma unroll
             for (int J = 0; J <= I; ++J)
-                acc[I * (I + 1) / 2 + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], g[J], acc[I * (I + 1) / 2 + J], 0, 0, 0);
+                acc[h2][I * (I + 1) / 2 + J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], g[J], acc[h2][I * (I + 1) / 2 + J], 0, 0, 0);
+    };
+    {
+        double D0, t0, g0[NB], D1, t1, g1[NB];
+        fetch(D0, t0, g0);
+        int ks = 0;
+        for (; ks + 1 < nks; ks += 2) {
+            fetch(D1, t1, g1);
+            multiply(std::integral_constant<int, 0>{}, D0, t0, g0);
+            fetch(D0, t0, g0);                      // (past the end: zero rows, never multiplied)
+            multiply(std::integral_constant<int, NACC - 1>{}, D1, t1, g1);
+        }
+        if (ks < nks) multiply(std::integral_constant<int, 0>{}, D0, t0, g0);
     }
+    static_assert(WaveLds<SH>::RED >= 2 * (SH::NDP + 4), "look-ahead of the MFMA pass stays inside the transposition tile");
+    double *mtk = mt + kq * (NV + 1) + c;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -305,9 +356,10 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, int nks, const d
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int row = 16 * I + kq + 4 * reg, col = 16 * J + c;
-                const double v = acc[I * (I + 1) / 2 + J][reg];
+                double v = acc[0][I * (I + 1) / 2 + J][reg];
+                if constexpr (NACC == 2) v += acc[1][I * (I + 1) / 2 + J][reg];
                 if (row < NV && col < NV) {
-                    mt[row * (NV + 1) + col] = v;
+                    mtk[(16 * I + 4 * reg) * (NV + 1) + 16 * J] = v;
                     if (I != J) mt[col * (NV + 1) + row] = v;
                 }
                 if (I == IT && row == NV && col < NV) gdr[col] = v;
@@ -363,13 +415,17 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
     using WL = WaveLds<SH>;
     constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, KT = SH::KT, WCAP = SH::WCAP, LDG = SH::LDG;
+#ifdef TMPC_HOST_SIM
+    double *smem = sim::lds<double>();
+#else
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#endif
     double *wbase = smem;                      // WPB per-wave workspaces
     double *Hct = wbase + WPB * WL::TOTAL;     // [KC][NCCP]
     double *Psi = Hct + KC * NCCP;             // [KC][NV]
-    double *Hs = Psi + KC * NV;                // [NV][NV]
-    double *Hinv = Hs + NV * NV;               // [NV][NV]
-    double *Gt = Hinv + NV * NV;               // [grows + 1][LDG]  dense functionals in use, row-major (odd stride), then a zero row
+    double *Hs = Psi + KC * NV;                // [NV][LDH]
+    double *Hinv = Hs + NV * SH::LDH;          // [NV][LDH]
+    double *Gt = Hinv + NV * SH::LDH;              // [grows + ZERO_ROWS][LDG]  dense functionals in use, row-major (odd stride), then zero rows
     const int grows = 4 * qp.nks;              // (last in the layout: its size is the only one that depends on the problem)
 
     const int tid = threadIdx.x;
@@ -379,10 +435,10 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nc = qp.nc;
 
     // ---- stage the shared model once per workgroup (coalesced, L2-resident source)
-    for (int i = tid; i < (grows + 1) * LDG; i += blockDim.x) Gt[i] = (i < grows * LDG) ? qp.Gt[i] : 0.0;
+    for (int i = tid; i < (grows + ZERO_ROWS) * LDG; i += blockDim.x) Gt[i] = (i < grows * LDG) ? qp.Gt[i] : 0.0;
     for (int i = tid; i < KC * NCCP; i += blockDim.x) Hct[i] = qp.Hct[i];
     for (int i = tid; i < KC * NV; i += blockDim.x) Psi[i] = qp.Psi[i];
-    for (int i = tid; i < NV * NV; i += blockDim.x) { Hs[i] = qp.Hs[i]; Hinv[i] = qp.Hinv[i]; }
+    for (int i = tid; i < NV * NV; i += blockDim.x) { const int r_ = i / NV, c_ = i - r_ * NV; Hs[r_ * SH::LDH + c_] = qp.Hs[i]; Hinv[r_ * SH::LDH + c_] = qp.Hinv[i]; }
     __syncthreads();
 
     double *red = wbase + wave * WL::TOTAL;       // transposition tile / refinement workspace
@@ -504,7 +560,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (lane < NV) {
                 double v = 0.0;
 #pragma unroll
-                for (int j = 0; j < NV; ++j) v -= Hinv[lane * NV + j] * qv[j];
+                for (int j = 0; j < NV; ++j) v -= Hinv[lane * SH::LDH + j] * qv[j];
                 zv[lane] = v;
             }
             wave_lds_fence();
@@ -668,11 +724,12 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         if (lane < NV) sums[lane] = v1;
                         wave_lds_fence();
                     }
-                    double lmax = 0.0;
+                    // |r_p| and max lambda are only ever compared with thresholds: a ballot each instead of a reduction
+                    double lmax_l = 0.0;
 #pragma unroll
-                    for (int i = 0; i < RS; ++i) lmax = vmax(lmax, lam[i]);
-                    const double rpn = wave_max(rpn_l);
-                    lmax = wave_max(lmax);
+                    for (int i = 0; i < RS; ++i) lmax_l = vmax(lmax_l, lam[i]);
+                    const bool rp_small = !__any(rpn_l > try_tol * hn);
+                    const bool lam_big = __any(lmax_l > 1e10);
                     const double gap = wave_sum(gap_l);
                     const double mu = gap / ncd;
                     STAMP(1);
@@ -681,7 +738,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     if (lane < NV) {
                         double v = 0.0;
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) v += Hs[lane * NV + j] * zv[j];
+                        for (int j = 0; j < NV; ++j) v += Hs[lane * SH::LDH + j] * zv[j];
                         cgv[lane] = v + qv[lane];
                     }
                     wave_lds_fence();
@@ -696,8 +753,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     STAMP(2);
                     // The dual residual needs G'lam, which nothing else uses: it is formed (one more pass over the functionals)
                     // only when the primal residual and the gap already pass, or when the multipliers blow up (Farkas test).
-                    const bool near = (rpn <= try_tol * hn) && (gap <= try_tol * objs);
-                    if (near || lmax > 1e10) {
+                    const bool near = rp_small && (gap <= try_tol * objs);
+                    if (near || lam_big) {
                         if constexpr (FD > 0) {
                             double accl[NV];
 #pragma unroll
@@ -748,8 +805,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         if (lane == 0 && b < 2) printf("b %lld it %d rdn %.3e qn %.3e\n", (long long)b, it, rdn, qn);
 #endif
                         if (near && rdn <= 1e3 * try_tol * qn) { want_polish = true; rdn_last = readlane_d(rdn, 0); mu_hand = readlane_d(mu, 0); break; }
-                        if (lmax > 1e10) {
+                        if (lam_big) {
                             // Farkas-type certificate: lam blows up, G'lam -> 0, h'lam < 0
+                            const double lmax = wave_max(lmax_l);
                             double hl = 0.0;       // (h is formed on the fly: its LDS region holds r_p here)
 #pragma unroll
                             for (int i = 0; i < RS; ++i) {
@@ -763,7 +821,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         }
                     }
 #ifdef TMPC_DEBUG_PRINT
-                    if (lane == 0 && b < 2) printf("b %lld it %d gap %.3e objs %.3e rpn %.3e hn %.3e lmax %.3e near %d tol %.1e\n", (long long)b, it, gap, objs, rpn, hn, lmax, (int)near, try_tol);
+                    if (lane == 0 && b < 2) printf("b %lld it %d gap %.3e objs %.3e hn %.3e near %d tol %.1e\n", (long long)b, it, gap, objs, hn, (int)near, try_tol);
 #endif
                     if (gap <= 1e-15 * objs) { st = TMPC_STATUS_MAX_ITER; break; }
                     // ---- M = Hs + G'DG by rows (lane i holds row i), elimination with the predictor rhs carried along
@@ -784,7 +842,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     const int e = lane + q * WAVE;
                                     if (e < NV * NV) {
                                         const int i = e / NV, j = e - i * NV;
-                                        double v = Hs[e];
+                                        double v = Hs[i * SH::LDH + j];
                                         if constexpr (FD > 0) v += Mf[i * (NV + 1) + j];
                                         if constexpr (KC > 0) {
 #pragma unroll
@@ -1023,9 +1081,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (!h_valid) { compute_h(); h_valid = true; }
             {
                 // workspace carved from the (now idle) transposition tile
-                double *GW = red;                         // [WCAP][NV]  rows of the working set, expanded (sign included)
-                double *T = GW + WCAP * NV;               // [NV][WCAP]
-                double *yv = T + NV * WCAP;               // [WCAP]
+                double *GW = red;                         // [WCAP][LDH]  rows of the working set, expanded (sign included)
+                double *T = GW + WCAP * SH::LDH;          // [NV][LDT]
+                double *yv = T + NV * SH::LDT;            // [WCAP]
                 double *dyv = yv + WCAP;                  // [WCAP]
                 int *Widx = reinterpret_cast<int *>(dyv + WCAP);   // [WCAP] row ids: side * 64 + lane
                 double *zpv = dzav;                       // the refinement's iterate
@@ -1077,7 +1135,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         if (lane < NV) {
                             double v = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) v -= Hinv[lane * NV + j] * qv[j];
+                            for (int j = 0; j < NV; ++j) v -= Hinv[lane * SH::LDH + j] * qv[j];
                             zpv[lane] = v;
                         }
                         wave_lds_fence();
@@ -1100,7 +1158,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     for (int a = 0; a < KC; ++a) v += Hct[a * NCCP + r] * Psi[a * NV + j];
                                 }
                             }
-                            GW[idx] = sgn * v;
+                            GW[k * SH::LDH + j] = sgn * v;
                         }
                         wave_lds_fence();
                         // T = Hinv G_W'  (entry (i,k): i = idx / m, k = idx % m)
@@ -1108,8 +1166,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const int i = idx / m, k = idx - i * m;
                             double v = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) v += Hinv[i * NV + j] * GW[k * NV + j];
-                            T[i * WCAP + k] = v;
+                            for (int j = 0; j < NV; ++j) v += Hinv[i * SH::LDH + j] * GW[k * SH::LDH + j];
+                            T[i * SH::LDT + k] = v;
                         }
                         wave_lds_fence();
                         STAMP(11);
@@ -1124,13 +1182,13 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             double gw[NV];
                             const int la = lane < m ? lane : 0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) gw[j] = GW[la * NV + j];
+                            for (int j = 0; j < NV; ++j) gw[j] = GW[la * SH::LDH + j];
                             double sdiag = 0.0;
 #pragma unroll
                             for (int c2 = 0; c2 < MC; ++c2) {
                                 double v = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v += gw[j] * T[j * WCAP + c2];
+                                for (int j = 0; j < NV; ++j) v += gw[j] * T[j * SH::LDT + c2];
                                 const bool in = lane < m && c2 < m;
                                 srow[c2] = in ? v : ((c2 == lane) ? 1.0 : 0.0);
                                 if (c2 == lane && in) sdiag = v;
@@ -1153,8 +1211,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             if (lane < NV) {
                                 double v = qv[lane];
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v += Hs[lane * NV + j] * zpv[j];
-                                for (int k = 0; k < m; ++k) v += GW[k * NV + lane] * yv[k];
+                                for (int j = 0; j < NV; ++j) v += Hs[lane * SH::LDH + j] * zpv[j];
+                                for (int k = 0; k < m; ++k) v += GW[k * SH::LDH + lane] * yv[k];
                                 tv[lane] = v;
                             }
                             wave_lds_fence();
@@ -1162,7 +1220,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             if (lane < NV) {
                                 double v = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) v += Hinv[lane * NV + j] * tv[j];
+                                for (int j = 0; j < NV; ++j) v += Hinv[lane * SH::LDH + j] * tv[j];
                                 uv[lane] = v;
                             }
                             wave_lds_fence();
@@ -1171,7 +1229,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             if (lane < m) {
                                 double gz = 0.0, gt = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * NV + j]; gz += g * zpv[j]; gt += g * uv[j]; }
+                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * SH::LDH + j]; gz += g * zpv[j]; gt += g * uv[j]; }
                                 bb = gz - hw[Widx[lane]] - gt;
                             }
                             lanes_forward<MC>(srow, bb, lane);
@@ -1182,7 +1240,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             double dzl = 0.0, zl = 0.0;
                             if (lane < NV) {
                                 double v = uv[lane];
-                                for (int k = 0; k < m; ++k) v += T[lane * WCAP + k] * dyv[k];
+                                for (int k = 0; k < m; ++k) v += T[lane * SH::LDT + k] * dyv[k];
                                 zl = zpv[lane] - v;
                                 zpv[lane] = zl;
                                 dzl = fabs(v);
@@ -1368,7 +1426,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
 // LDS of a workgroup: per-wave workspaces, the shared model, and `grows` (+ 1 zero) rows of the dense functionals
 template <class SH>
 constexpr size_t kernel_lds_bytes(int wpb, int grows) {
-    return sizeof(double) * (static_cast<size_t>(SH::LDG) * (grows + 1) + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::NV +
+    return sizeof(double) * (static_cast<size_t>(SH::LDG) * (grows + ZERO_ROWS) + SH::KC * SH::NCCP + SH::KC * SH::NV + 2 * SH::NV * SH::LDH +
                              static_cast<size_t>(wpb) * WaveLds<SH>::TOTAL);
 }
 // rows of dense functionals the shapes are sized for: one slot in full, 96 of the 128 of two slots (cartpole N = 20: 92 / 93)
@@ -1385,6 +1443,26 @@ constexpr int waves_per_block() {
     return kernel_lds_bytes<SH>(4, gr) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3, gr) <= 160 * 1024 ? 3 : 2);
 }
 
+#ifdef TMPC_HOST_SIM
+// tests/wavesim: one workgroup of WPB waves on the host execution model; the persistent grid is that one workgroup
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
+hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
+                      const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
+                      int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, WorkCounter *wc, int n_cu,
+                      hipStream_t stream) {
+    using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
+    const size_t lds = kernel_lds_bytes<SH>(WPB, 4 * qp.nks);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    (void)n_cu; (void)stream; (void)wc;
+    unsigned long long next_item = 0;
+    sim::Dim3 bi, gd;
+    sim_rendezvous_total += sim::run_block(WAVE * WPB, lds, bi, gd, [&]() {
+        solve_kernel<NV, DP, DS, KC, CP, CS, WPB>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters,
+                                                  ws_in, ws_out, &next_item);
+    });
+    return hipSuccess;
+}
+#else
 template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
 hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
@@ -1428,6 +1506,8 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     ++wc->pos;
     return hipGetLastError();
 }
+
+#endif
 
 }  // namespace
 

@@ -1,7 +1,11 @@
 // Wave-level device helpers shared by the block kernel (tmpc_block.hip) and the LP kernel (tmpc_lp.hip): DPP / readlane
 // reductions over the 64 lanes of a gfx950 wavefront and a division-free reciprocal.
 #pragma once
+#ifdef TMPC_HOST_SIM
+#include "hip_sim.hpp"      // tests/wavesim: the same source compiled for the CPU (sanitizer runs), never in the product
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <utility>
 
@@ -33,6 +37,11 @@ __device__ __forceinline__ double readlane_d(double v, int l) {
 // max / min as the bare instruction.  `fmax` compiles to v_max_f64 preceded by a canonicalising v_max_f64 x, x of every
 // operand the compiler cannot prove quiet (2-3 instructions per call in the row sweeps); the instruction itself already
 // returns the other operand when one is a NaN, which is all these reductions need.
+#ifdef TMPC_HOST_SIM
+__device__ __forceinline__ double vmax(double a, double b) { return fmax(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return fmin(a, b); }
+__device__ __forceinline__ double vmax_abs(double a, double b) { return fmax(a, fabs(b)); }
+#else
 __device__ __forceinline__ double vmax(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -48,6 +57,7 @@ __device__ __forceinline__ double vmax_abs(double a, double b) {      // max(a, 
     asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+#endif
 struct OpSum { __device__ __forceinline__ static double f(double a, double b) { return a + b; } };
 struct OpMin { __device__ __forceinline__ static double f(double a, double b) { return vmin(a, b); } };
 struct OpMax { __device__ __forceinline__ static double f(double a, double b) { return vmax(a, b); } };
@@ -64,7 +74,11 @@ __device__ __forceinline__ double wave_reduce(double v) {
 }
 
 // Orders one wave's LDS traffic for the compiler (the hardware runs the DS instructions of a wave in issue order).
+#ifdef TMPC_HOST_SIM
+__device__ __forceinline__ void lds_fence() { sim::wave_fence(); }
+#else
 __device__ __forceinline__ void lds_fence() { asm volatile("" ::: "memory"); }
+#endif
 
 // Sum each of acc[0..CNT) over the 64 lanes, totals to out[0..CNT) (LDS).  `red` is a [16][68] tile: 16 entries per round
 // are written as rows (lane l at column l + l/16), lane l then adds the 16-lane quarter (l & 3) of entry (l >> 2) and
