@@ -25,8 +25,11 @@
 extern "C" {
 #endif
 
-/* 1: first cut; 2: projected terminal rows of the packet-received problem (HTP, hTP, rTP); 3: tmpc_lp_batch, TMPC_STATUS_UNBOUNDED */
-#define TMPC_ABI_VERSION 4
+/* 1: first cut; 2: projected terminal rows of the packet-received problem (HTP, hTP, rTP); 3: tmpc_lp_batch, TMPC_STATUS_UNBOUNDED;
+ * 4: terminal_equality, tmpc_kernel_name; 5: an iterate that hits the iteration cap keeps TMPC_STATUS_MAX_ITER whatever its
+ * constraint violation (INFEASIBLE only with a Farkas-type certificate), host-only handles report their kernel path,
+ * tmpc_debug_dump_layout */
+#define TMPC_ABI_VERSION 5
 
 /* error codes (function return values) */
 #define TMPC_OK            0
@@ -183,13 +186,14 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant);
 const char *tmpc_kernel_name(const tmpc_handle *h, int variant);
 
 /*
- * Diagnostics (tests/wavesim: the kernel sources compiled for the CPU under sanitizers): a copy of the structure the
- * wave-per-QP kernel receives for `variant` (tmpc::DeviceQP of csrc/tmpc_device.hpp, `wave_qp_bytes` must be its size),
- * its compiled shape (NVP, DP, DS, KC, CP, CS) and whether a shape covers the variant.  For a host-only handle
- * (device < 0) every pointer in the copy is a HOST pointer owned by the handle; for a device handle they are device
- * pointers.  Not part of the solve path.
+ * Diagnostics (tests/wavesim: the kernel sources compiled for the CPU under sanitizers): writes to `path` everything the
+ * wave-per-QP kernel receives for `variant` -- the compiled shape (NVP, DP, DS, KC, CP, CS; int32 x 6), the size of
+ * tmpc::DeviceQP (csrc/tmpc_device.hpp; uint64) and the structure itself, then, for each of its arrays in field order
+ * (Gt, Hct, Psi, Hs, Hinv, F1s, F2s, g0p, Esp, vmask, row_of, gp0, Ep, Dv, Tzs, Txf, Mth, A, B), a uint64 byte count and
+ * the bytes.  Host-only handles (device < 0) only: TMPC_E_UNSUPPORTED otherwise, or when no wave shape covers the variant.
+ * Not part of the solve path.
  */
-int tmpc_debug_layout(const tmpc_handle *h, int variant, void *wave_qp, size_t wave_qp_bytes, int32_t shape[6], int *wave_ok);
+int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path);
 
 /*
  * Device-resident closed loop over a lossy network for B independent trajectories and T time steps: the body

@@ -12,7 +12,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(_PKG, "lib", "libtmpc_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _PTR_FIELDS = ["A", "B", "Q", "R", "P", "T", "K", "K_anc",
                "Hx", "hx", "Hu", "hu", "HT", "hT", "HZ", "hZ", "HZW", "hZW", "HTP", "hTP"]

@@ -29,6 +29,7 @@ struct Variant {
     tmpc::BlockQP bq{};
     int tiles = 0;               // block kernel: NVP / 16 (0: not available)
     std::vector<void *> dev;     // device allocations of this variant
+    std::vector<size_t> dev_bytes;       // their sizes (tmpc_debug_dump_layout)
 };
 
 }  // namespace
@@ -104,12 +105,14 @@ int upload(tmpc_handle *h, Variant &v, const T *src, size_t n, const T **dst) {
         p = std::malloc((n ? n : 1) * sizeof(T));
         if (!p) { h->err = "out of memory"; return TMPC_E_NOMEM; }
         v.dev.push_back(p);
+        v.dev_bytes.push_back(n * sizeof(T));
         if (n) std::memcpy(p, src, n * sizeof(T));
         *dst = static_cast<const T *>(p);
         return TMPC_OK;
     }
     HIP_TRY(h, hipMalloc(&p, (n ? n : 1) * sizeof(T)));
     v.dev.push_back(p);
+    v.dev_bytes.push_back(n * sizeof(T));
     if (n) HIP_TRY(h, hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T *>(p);
     return TMPC_OK;
@@ -637,15 +640,30 @@ int tmpc_get_kernel_path(const tmpc_handle *h, int variant) {
     return use_block(h, h->v[variant]) ? TMPC_PATH_BLOCK : TMPC_PATH_WAVE;       // (host-only handles included: the choice is made at tmpc_create)
 }
 
-int tmpc_debug_layout(const tmpc_handle *h, int variant, void *wave_qp, size_t wave_qp_bytes, int32_t shape[6], int *wave_ok) {
-    if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path) {
+    if (!h || !path || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    if (h->device >= 0) return TMPC_E_UNSUPPORTED;            // the arrays of a device handle live in HBM
     const Variant &v = h->v[variant];
-    if (wave_qp) {
-        if (wave_qp_bytes != sizeof(tmpc::DeviceQP)) return TMPC_E_INVALID;
-        std::memcpy(wave_qp, &v.d, sizeof(tmpc::DeviceQP));
+    if (!v.wave_ok) return TMPC_E_UNSUPPORTED;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return TMPC_E_INVALID;
+    const int32_t shp[6] = {v.shape.nvp, v.shape.dp, v.shape.ds, v.shape.kcp, v.shape.cp, v.shape.cs};
+    const uint64_t qp_bytes = sizeof(tmpc::DeviceQP);
+    std::fwrite(shp, 4, 6, f);
+    std::fwrite(&qp_bytes, 8, 1, f);
+    std::fwrite(&v.d, sizeof(tmpc::DeviceQP), 1, f);
+    // every array the structure points to, in the order of its fields: byte count, bytes (0: null pointer)
+    const void *ptrs[] = {v.d.Gt, v.d.Hct, v.d.Psi, v.d.Hs, v.d.Hinv, v.d.F1s, v.d.F2s, v.d.g0p, v.d.Esp, v.d.vmask, v.d.row_of,
+                          v.d.gp0, v.d.Ep, v.d.Dv, v.d.Tzs, v.d.Txf, v.d.Mth, v.d.A, v.d.B};
+    for (const void *q : ptrs) {
+        uint64_t n = 0;
+        if (q)
+            for (size_t i = 0; i < v.dev.size(); ++i)
+                if (v.dev[i] == q) { n = v.dev_bytes[i]; break; }
+        std::fwrite(&n, 8, 1, f);
+        if (n) std::fwrite(q, 1, n, f);
     }
-    if (shape) { shape[0] = v.shape.nvp; shape[1] = v.shape.dp; shape[2] = v.shape.ds; shape[3] = v.shape.kcp; shape[4] = v.shape.cp; shape[5] = v.shape.cs; }
-    if (wave_ok) *wave_ok = v.wave_ok ? 1 : 0;
+    std::fclose(f);
     return TMPC_OK;
 }
 

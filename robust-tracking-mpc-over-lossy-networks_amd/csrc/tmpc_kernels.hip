@@ -1456,6 +1456,7 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     (void)n_cu; (void)stream; (void)wc;
     unsigned long long next_item = 0;
     sim::Dim3 bi, gd;
+    bi.x = bi.y = bi.z = 0;                    // workgroup 0 of a grid of one
     sim_rendezvous_total += sim::run_block(WAVE * WPB, lds, bi, gd, [&]() {
         solve_kernel<NV, DP, DS, KC, CP, CS, WPB>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters,
                                                   ws_in, ws_out, &next_item);
@@ -1511,13 +1512,20 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
 
 }  // namespace
 
+#ifdef TMPC_HOST_SIM
+unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
+#endif
+
 // Compiled shapes (NVP, DP, DS, KC, CP, CS): padded variables; 64-functional slots of dense paired / dense single rows; width
 // of the factored block and its paired / single slots.  Dense-single-only shapes cover the small and the irregular problems
 // (config 1); the paired + factored shapes cover the cartpole: base problem at N <= 11 (bench) and N <= 23 (the reference's
 // N = 20; terminal block of 420 rows = 210 functionals of width 5), packet-received problem at N <= 11 and N <= 23
 // (initial-state block Z (-) W of 854 rows = 427 functionals of width 4).
-#ifdef TMPC_ONLY_BENCH
+#if defined(TMPC_ONLY_BENCH)
 #define TMPC_SHAPES(X) X(12, 1, 0, 5, 4, 0)
+#elif defined(TMPC_SIM_SHAPES)
+// tests/wavesim: the bench shape (paired + factored functionals) and the shape of BASELINE config 1 (all rows dense and single)
+#define TMPC_SHAPES(X) X(12, 1, 0, 5, 4, 0) X(8, 0, 2, 0, 0, 0)
 #else
 #define TMPC_SHAPES(X) \
     X(8, 0, 2, 0, 0, 0) X(8, 0, 4, 0, 0, 0) X(12, 0, 2, 0, 0, 0) X(12, 0, 4, 0, 0, 0) X(16, 0, 2, 0, 0, 0) X(16, 0, 4, 0, 0, 0) \

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     L = hip_lib.lib()
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/tmpc.h but not exported"
-    assert L.tmpc_abi_version() == 4
+    assert L.tmpc_abi_version() == 5
 
 
 def test_struct_layout_matches_header(hip_lib):

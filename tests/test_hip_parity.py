@@ -28,7 +28,7 @@ def cartpole(hip_lib, oracle_lib):
 
 def test_native_library_is_the_one_in_tree(hip_lib):
     assert os.path.samefile(hip_lib.LIB_PATH, os.path.join(common.PKG, "lib", "libtmpc_hip.so"))
-    assert hip_lib.lib().tmpc_abi_version() == 4
+    assert hip_lib.lib().tmpc_abi_version() == 5
 
 
 def test_golden_fixture_cartpole_N10(cartpole, hip_lib):

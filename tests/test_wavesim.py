@@ -1,0 +1,111 @@
+"""The wave-per-QP kernel's SOURCE (csrc/tmpc_kernels.hip, the text the GPU build compiles) on a host execution model, under
+sanitizers.  CPU only; no GPU sanitizer exists on the pool, and a build of this kernel that spilled 126 registers once
+returned wrong statuses on the GPU: was that the spill code, or undefined behaviour in the source that only some register
+allocations expose?  tests/wavesim/hip_sim.hpp runs every lane as a fiber and makes the wavefront's guarantees explicit
+(cross-lane operations, LDS fences and barriers are rendezvous), so that
+
+* AddressSanitizer + UndefinedBehaviorSanitizer see every LDS / global access and every arithmetic operation,
+* MemorySanitizer sees every read of a register or LDS word that was never written (LDS, outputs and the work space
+  start out poisoned),
+* an LDS hand-over between lanes without a fence in between reads stale data (and the answers differ from the oracle's),
+* a cross-lane operation under divergent control flow is a reported deadlock.
+
+The layouts the kernel reads are the product's own (tmpc_create on a host-only handle, tmpc_debug_dump_layout)."""
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import common
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "wavesim"))
+import run_case  # noqa: E402
+
+S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
+SAN_ENV = {"ASAN_OPTIONS": "detect_stack_use_after_return=0:detect_leaks=1:abort_on_error=0", "UBSAN_OPTIONS": "print_stacktrace=1:halt_on_error=1",
+           "MSAN_OPTIONS": "halt_on_error=1"}
+CLEAN_MARKERS = ("ERROR: AddressSanitizer", "runtime error:", "WARNING: MemorySanitizer", "ERROR: LeakSanitizer")
+
+
+@pytest.fixture(scope="module")
+def binaries():
+    # (also built by __graft_entry__.build(); make leaves them alone when they are up to date)
+    return {t: run_case.build(t, "-DTMPC_SIM_SHAPES") for t in ("wavesim", "wavesim_asan", "wavesim_msan")}
+
+
+@pytest.fixture(scope="module")
+def cartpole():
+    mpc, _ = common.make_mpc("cartpole", 10, True, create=False)
+    return mpc._problem_dict()
+
+
+def assert_clean(out):
+    for m in CLEAN_MARKERS:
+        assert m not in out["stderr"], out["stderr"][-4000:]
+
+
+def test_all_fixture_instances_through_the_kernel_source(binaries, cartpole, oracle_lib):
+    """All 600 closed-loop states of the committed fixture: statuses bit-identical with the oracle's, u_nom to 1e-8 (the GPU
+    parity tolerance), iteration counts in the same range.  Eight processes, one workgroup of eight waves each."""
+    from oracle.oracle import Oracle
+    ref = Oracle(cartpole).solve(S[:, :4], S[:, 4:])
+    chunks = np.array_split(np.arange(len(S)), 8)
+    with ThreadPoolExecutor(8) as ex:
+        outs = list(ex.map(lambda ii: run_case.run(binaries["wavesim"], cartpole, S[ii, :4], S[ii, 4:]), chunks))
+    st = np.concatenate([o["status"] for o in outs])
+    u = np.concatenate([o["u_nom"] for o in outs])
+    it = np.concatenate([o["iters"] for o in outs])
+    assert np.array_equal(st, ref["status"]) and np.all(st == 0)
+    assert np.max(np.abs(u - ref["u_nom"])) < 1e-8
+    assert np.max(np.abs(np.concatenate([o["xu_ss"] for o in outs]) - ref["xu_ss"])) < 1e-8
+    assert it.min() >= 0 and it.max() < 40 and abs(it.mean() - ref["iters"].mean()) < 2.0
+    assert sum(o["rendezvous"] for o in outs) > 1e6          # the wavefront model was exercised, not bypassed
+
+
+def test_address_and_undefined_behaviour_sanitizers_are_clean(binaries, cartpole, oracle_lib):
+    from oracle.oracle import Oracle
+    idx = np.arange(0, 600, 10)              # 60 instances, transients and settled states alike
+    parts = np.array_split(idx, 6)
+    with ThreadPoolExecutor(6) as ex:
+        outs = list(ex.map(lambda ii: run_case.run(binaries["wavesim_asan"], cartpole, S[ii, :4], S[ii, 4:], env=SAN_ENV), parts))
+    for o in outs:
+        assert_clean(o)
+    ref = Oracle(cartpole).solve(S[idx, :4], S[idx, 4:])
+    assert np.array_equal(np.concatenate([o["status"] for o in outs]), ref["status"])
+    assert np.max(np.abs(np.concatenate([o["u_nom"] for o in outs]) - ref["u_nom"])) < 1e-8
+
+
+def test_memory_sanitizer_is_clean(binaries, cartpole, oracle_lib):
+    """No register, LDS word or output element is read before it is written (the outputs are checked when the program
+    writes them to its file)."""
+    from oracle.oracle import Oracle
+    idx = np.arange(3, 600, 15)              # 40 instances
+    parts = np.array_split(idx, 5)
+    with ThreadPoolExecutor(5) as ex:
+        outs = list(ex.map(lambda ii: run_case.run(binaries["wavesim_msan"], cartpole, S[ii, :4], S[ii, 4:], env=SAN_ENV), parts))
+    for o in outs:
+        assert_clean(o)
+    ref = Oracle(cartpole).solve(S[idx, :4], S[idx, 4:])
+    assert np.array_equal(np.concatenate([o["status"] for o in outs]), ref["status"])
+
+
+def test_edge_cases_and_the_dense_single_shape_under_sanitizers(binaries, oracle_lib):
+    """BASELINE config 1 (double integrator, free x_0: every row dense and single, no factored block: another instantiation)
+    with feasible, trivially optimal and infeasible instances, all three builds."""
+    from oracle.oracle import Oracle
+    mpc, _ = common.make_mpc("double_integrator", 5, False, create=False)
+    d = mpc._problem_dict()
+    rng = np.random.default_rng(4)
+    X = np.r_[rng.uniform(-1, 1, (20, 2)) * [7.5, 0.9], [[0.0, 0.0]], [[30.0, 0.0]], [[-3.1437307257161446, 0.5378281719126672]]]
+    R = np.c_[np.r_[rng.uniform(-9, 9, 20), 0.0, 0.0, 4.697848229977945], np.zeros(len(X))]
+    ref = Oracle(d).solve(X, R)
+    assert 0 in ref["status"] and 2 in ref["status"] and ref["iters"][20] == 0
+    for t in ("wavesim", "wavesim_asan", "wavesim_msan"):
+        o = run_case.run(binaries[t], d, X, R, env=SAN_ENV)
+        assert_clean(o)
+        assert np.array_equal(o["status"], ref["status"]), (t, o["status"], ref["status"])
+        ok = ref["status"] == 0
+        assert np.max(np.abs(o["u_nom"][ok] - ref["u_nom"][ok])) < 1e-8
+        assert np.all(np.isnan(o["u_nom"][~ok]))

@@ -336,9 +336,10 @@ inline double __longlong_as_double(long long u) { double v; std::memcpy(&v, &u, 
 inline unsigned __float_as_uint(float f) { unsigned u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(unsigned u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline unsigned long long atomicAdd(unsigned long long *p, unsigned long long v) { const unsigned long long o = *p; *p = o + v; return o; }
-#define __ATOMIC_RELAXED_SIM 0
-#define __HIP_MEMORY_SCOPE_AGENT 0
-template <class T> inline T __hip_atomic_load(const T *p, int, int) { return *p; }
+// (__hip_atomic_load is a clang builtin on the host as well; its scope constants come with the HIP language mode)
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
 using std::fabs;
 using std::fma;
 using std::fmax;

@@ -1,0 +1,64 @@
+"""TEST INFRASTRUCTURE: has the product library dump the wave kernel's input layout for a problem (host-only handle,
+tmpc_debug_dump_layout), writes the batch, runs a wavesim binary on both, reads its output
+(tests/wavesim/wavesim_main.cpp has the formats)."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+
+
+def build(target="wavesim", extra=""):
+    subprocess.check_call(["make", "-s", "-C", HERE, f"_build/{target}"] + ([f"EXTRA={extra}"] if extra else []))
+    return os.path.join(BUILD, target)
+
+
+def run(binary, d, X, R, variant=None, env=None, timeout=1800):
+    from LinearMPCOverNetworks import _native
+    L = _native.lib()
+    L.tmpc_debug_dump_layout.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    h = _native.create(d, -1)
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            lays = []
+            for k in range(2 if variant is not None else 1):
+                path = os.path.join(tmp, f"layout{k}.bin")
+                rc = L.tmpc_debug_dump_layout(h.ptr, k, path.encode())
+                if rc != 0:
+                    raise RuntimeError(f"tmpc_debug_dump_layout({k}) failed: {rc}")
+                lays.append(path)
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            R = np.ascontiguousarray(R, dtype=np.float64)
+            B, nx = X.shape
+            batch, out = os.path.join(tmp, "batch.bin"), os.path.join(tmp, "out.bin")
+            with open(batch, "wb") as f:
+                np.array([B, nx], dtype=np.int64).tofile(f)
+                X.tofile(f)
+                R.tofile(f)
+                np.array([0 if variant is None else 1], dtype=np.int64).tofile(f)
+                if variant is not None:
+                    np.ascontiguousarray(np.broadcast_to(np.asarray(variant, dtype=np.uint8), (B,))).tofile(f)
+            res = subprocess.run([binary] + lays + [batch, out], capture_output=True, text=True, timeout=timeout,
+                                 env=dict(os.environ, **(env or {})))
+            if res.returncode != 0:
+                raise RuntimeError(f"{os.path.basename(binary)} failed ({res.returncode}):\n{res.stderr[-8000:]}")
+            nu, N = h.nu, h.N
+            raw = open(out, "rb").read()
+            off = 0
+
+            def take(n, dt):
+                nonlocal off
+                a = np.frombuffer(raw, dtype=dt, count=n, offset=off)
+                off += a.nbytes
+                return a
+            o = dict(u_nom=take(B * N * nu, np.float64).reshape(B, N, nu), x_nom0=take(B * nx, np.float64).reshape(B, nx),
+                     xu_ss=take(B * (nx + nu), np.float64).reshape(B, nx + nu), status=take(B, np.int32), iters=take(B, np.int32))
+            o["rendezvous"] = int(take(1, np.uint64)[0])
+            o["stderr"] = res.stderr
+            return o
+    finally:
+        _native.destroy(h)

@@ -1,0 +1,103 @@
+// TEST INFRASTRUCTURE (not product code): runs csrc/tmpc_kernels.hip -- the wave-per-QP kernel, the same source text the
+// GPU build compiles -- on the host execution model of hip_sim.hpp, so that AddressSanitizer / UndefinedBehaviorSanitizer /
+// MemorySanitizer can watch it.  The kernel's input structure comes from the product library itself: a host-only handle
+// (tmpc_create with device < 0) condenses the problem and lays the model out exactly as it would for the GPU, and
+// tmpc_debug_dump_layout writes that layout to a file (tests/wavesim/run_case.py).  This program links nothing of the
+// product: every byte it reads is either that file or the batch.
+//
+//   wavesim <layout file> [<layout file of variant 1>] <batch file> <output file>
+// layout file: include/tmpc.h, tmpc_debug_dump_layout
+// batch file : int64 B, nx; x_k [B][nx], ref [B][nx] doubles; int64 has_variant; variant bytes [B]
+// output file: u_nom [B][N nu], x_nom0 [B][nx], xu_ss [B][nx+nu] doubles, status [B], iters [B] int32, then one uint64:
+//              wave rendezvous executed
+#include "../../robust-tracking-mpc-over-lossy-networks_amd/csrc/tmpc_kernels.hip"
+
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+namespace {
+void need(bool ok, const char *what) {
+    if (!ok) { std::fprintf(stderr, "wavesim: %s\n", what); std::exit(2); }
+}
+struct Layout {
+    tmpc::DeviceQP d;
+    tmpc::KernelShape ks;
+    std::vector<std::unique_ptr<char[]>> keep;
+};
+// every array gets a heap block of exactly its size (AddressSanitizer red zones right behind the last element)
+void read_layout(const char *path, Layout &L) {
+    FILE *f = std::fopen(path, "rb");
+    need(f != nullptr, "cannot open layout file");
+    int32_t shp[6];
+    uint64_t qb;
+    need(std::fread(shp, 4, 6, f) == 6 && std::fread(&qb, 8, 1, f) == 1, "short layout file");
+    need(qb == sizeof(tmpc::DeviceQP), "layout file written for another DeviceQP");
+    need(std::fread(&L.d, sizeof L.d, 1, f) == 1, "short layout file");
+    L.ks.nvp = shp[0]; L.ks.dp = shp[1]; L.ks.ds = shp[2]; L.ks.kcp = shp[3]; L.ks.cp = shp[4]; L.ks.cs = shp[5];
+    const void **fields[] = {reinterpret_cast<const void **>(&L.d.Gt), reinterpret_cast<const void **>(&L.d.Hct),
+                             reinterpret_cast<const void **>(&L.d.Psi), reinterpret_cast<const void **>(&L.d.Hs),
+                             reinterpret_cast<const void **>(&L.d.Hinv), reinterpret_cast<const void **>(&L.d.F1s),
+                             reinterpret_cast<const void **>(&L.d.F2s), reinterpret_cast<const void **>(&L.d.g0p),
+                             reinterpret_cast<const void **>(&L.d.Esp), reinterpret_cast<const void **>(&L.d.vmask),
+                             reinterpret_cast<const void **>(&L.d.row_of), reinterpret_cast<const void **>(&L.d.gp0),
+                             reinterpret_cast<const void **>(&L.d.Ep), reinterpret_cast<const void **>(&L.d.Dv),
+                             reinterpret_cast<const void **>(&L.d.Tzs), reinterpret_cast<const void **>(&L.d.Txf),
+                             reinterpret_cast<const void **>(&L.d.Mth), reinterpret_cast<const void **>(&L.d.A),
+                             reinterpret_cast<const void **>(&L.d.B)};
+    for (const void **fp : fields) {
+        uint64_t n;
+        need(std::fread(&n, 8, 1, f) == 1, "short layout file");
+        if (n == 0) { *fp = nullptr; continue; }
+        L.keep.emplace_back(new char[n]);
+        need(std::fread(L.keep.back().get(), 1, n, f) == n, "short layout file");
+        *fp = L.keep.back().get();
+    }
+    L.d.dbg = nullptr;
+    L.d.save = nullptr;
+    L.d.ticks = nullptr;
+    std::fclose(f);
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    need(argc == 4 || argc == 5, "usage: wavesim <layout> [<layout variant 1>] <batch> <out>");
+    const int nvar = argc - 3;
+    Layout lay[2];
+    for (int k = 0; k < nvar; ++k) read_layout(argv[1 + k], lay[k]);
+    FILE *f = std::fopen(argv[1 + nvar], "rb");
+    need(f != nullptr, "cannot open batch file");
+    int64_t B, nx, has_var;
+    need(std::fread(&B, 8, 1, f) == 1 && std::fread(&nx, 8, 1, f) == 1, "short batch file");
+    need(nx == lay[0].d.nx && B >= 0, "batch does not belong to this layout");
+    std::vector<double> xk(static_cast<size_t>(B * nx)), ref(xk.size());
+    need(std::fread(xk.data(), 8, xk.size(), f) == xk.size() && std::fread(ref.data(), 8, ref.size(), f) == ref.size(), "short batch file");
+    need(std::fread(&has_var, 8, 1, f) == 1, "short batch file");
+    std::vector<uint8_t> var(static_cast<size_t>(B), 0);
+    if (has_var) need(std::fread(var.data(), 1, var.size(), f) == var.size(), "short batch file");
+    std::fclose(f);
+    need(nvar == (has_var ? 2 : 1), "one layout per variant in use");
+
+    const int N = lay[0].d.N, nu = lay[0].d.nu;
+    // outputs start out uninitialised on purpose: what the kernel does not write stays poisoned for MemorySanitizer
+    std::unique_ptr<double[]> u(new double[static_cast<size_t>(B) * N * nu]), x0(new double[static_cast<size_t>(B) * nx]),
+        ss(new double[static_cast<size_t>(B) * (nx + nu)]);
+    std::unique_ptr<int32_t[]> st(new int32_t[static_cast<size_t>(B)]), it(new int32_t[static_cast<size_t>(B)]);
+    for (int k = 0; k < nvar; ++k) {
+        tmpc::WorkCounter wc;
+        const hipError_t e = tmpc::launch_solve(lay[k].d, lay[k].ks, k, B, xk.data(), ref.data(), has_var ? var.data() : nullptr, u.get(), x0.get(),
+                                               ss.get(), nullptr, st.get(), it.get(), nullptr, nullptr, &wc, 1, nullptr);
+        need(e == hipSuccess, "launch failed (shape not compiled into this build?)");
+        std::fprintf(stderr, "wavesim: %s, %lld instances\n", tmpc::kernel_name(lay[k].ks), static_cast<long long>(B));
+    }
+    FILE *o = std::fopen(argv[2 + nvar], "wb");
+    need(o != nullptr, "cannot open output file");
+    const size_t b = static_cast<size_t>(B);
+    need(std::fwrite(u.get(), 8, b * N * nu, o) == b * N * nu && std::fwrite(x0.get(), 8, b * nx, o) == b * nx &&
+         std::fwrite(ss.get(), 8, b * (nx + nu), o) == b * (nx + nu) && std::fwrite(st.get(), 4, b, o) == b && std::fwrite(it.get(), 4, b, o) == b,
+         "short write");
+    const uint64_t nr = tmpc::sim_rendezvous_count();
+    std::fwrite(&nr, 8, 1, o);
+    std::fclose(o);
+    return 0;
+}
