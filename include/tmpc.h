@@ -194,6 +194,10 @@ const char *tmpc_kernel_name(const tmpc_handle *h, int variant);
  * Not part of the solve path.
  */
 int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path);
+/* The same for the workgroup-per-QP kernel: tiles and workspace rows (int32 x 2), the sizes of tmpc::DeviceQP and
+ * tmpc::BlockQP (uint64 x 2), the two structures, then the arrays Hs, Hinv, F1s, F2s, gp0, Ep, Dv, Tzs, Txf, Mth, A, B of the
+ * first and Grm, Gcm, GHrm, g0, Es, ncols of the second, each as a uint64 byte count and the bytes. */
+int tmpc_debug_dump_block_layout(const tmpc_handle *h, int variant, const char *path);
 
 /*
  * Device-resident closed loop over a lossy network for B independent trajectories and T time steps: the body

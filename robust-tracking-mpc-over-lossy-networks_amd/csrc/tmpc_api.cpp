@@ -667,6 +667,33 @@ int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path) 
     return TMPC_OK;
 }
 
+int tmpc_debug_dump_block_layout(const tmpc_handle *h, int variant, const char *path) {
+    if (!h || !path || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    if (h->device >= 0) return TMPC_E_UNSUPPORTED;
+    const Variant &v = h->v[variant];
+    if (v.tiles == 0) return TMPC_E_UNSUPPORTED;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return TMPC_E_INVALID;
+    const int32_t hd[2] = {v.tiles, tmpc::block_workspace_rows()};
+    const uint64_t sz[2] = {sizeof(tmpc::DeviceQP), sizeof(tmpc::BlockQP)};
+    std::fwrite(hd, 4, 2, f);
+    std::fwrite(sz, 8, 2, f);
+    std::fwrite(&v.db, sizeof(tmpc::DeviceQP), 1, f);
+    std::fwrite(&v.bq, sizeof(tmpc::BlockQP), 1, f);
+    const void *ptrs[] = {v.db.Hs, v.db.Hinv, v.db.F1s, v.db.F2s, v.db.gp0, v.db.Ep, v.db.Dv, v.db.Tzs, v.db.Txf, v.db.Mth, v.db.A, v.db.B,
+                          v.bq.Grm, v.bq.Gcm, v.bq.GHrm, v.bq.g0, v.bq.Es, v.bq.ncols};
+    for (const void *q : ptrs) {
+        uint64_t n = 0;
+        if (q)
+            for (size_t i = 0; i < v.dev.size(); ++i)
+                if (v.dev[i] == q) { n = v.dev_bytes[i]; break; }
+        std::fwrite(&n, 8, 1, f);
+        if (n) std::fwrite(q, 1, n, f);
+    }
+    std::fclose(f);
+    return TMPC_OK;
+}
+
 const char *tmpc_kernel_name(const tmpc_handle *h, int variant) {
     if (!h || variant < 0 || variant >= h->nvariants) return "";
     const Variant &v = h->v[variant];

@@ -21,7 +21,11 @@
 //   * G'v products (two vectors per pass) use thread-per-(column, row part) over the row-major
 //     copy; G v products thread-per-row over the column-major copy; G z itself is carried along
 //     incrementally (G z += alpha G dz).
+#ifdef TMPC_HOST_SIM
+#include "hip_sim.hpp"      // tests/wavesim: this very source compiled for the CPU under sanitizers (never in the product)
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <atomic>
 #include <cmath>
@@ -700,7 +704,11 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
     using SH = BShape<T>;
     constexpr int NVP = SH::NVP, LDM = SH::LDM, WCAP = SH::WCAP, LDSS = SH::LDSS, BT = SH::BT;
+#ifdef TMPC_HOST_SIM
+    double *smem = sim::lds<double>();
+#else
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#endif
     double *big = smem;
     double *qv = big + SH::BIG;          // linear term
     double *zv = qv + NVP;               // z
@@ -1177,6 +1185,26 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
     }
 }
 
+#ifdef TMPC_HOST_SIM
+unsigned long sim_rendezvous_total = 0;
+// tests/wavesim: one workgroup on the host execution model takes the whole batch (grid of one)
+template <int T>
+hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int ws_blocks, int variant_id, int64_t B,
+                          const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
+                          double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
+    constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
+    static_assert(lds <= 160 * 1024, "block shape does not fit the 160 KiB LDS of a CU");
+    (void)ws_blocks; (void)stream;
+    sim::Dim3 bi, gd;
+    bi.x = bi.y = bi.z = 0;
+    sim_rendezvous_total += sim::run_block(BShape<T>::BT, lds, bi, gd, [&]() {
+        solve_block_kernel<T>(qp, bq, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
+    });
+    return hipSuccess;
+}
+template <int T>
+int block_occupancy_t() { return 1; }
+#else
 template <int T>
 hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int ws_blocks, int variant_id, int64_t B,
                           const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
@@ -1209,6 +1237,8 @@ int block_occupancy_t() {
     return nb;
 }
 
+#endif
+
 }  // namespace
 
 int block_tiles(int nv) {
@@ -1220,6 +1250,9 @@ int block_tiles(int nv) {
 }
 
 int block_workspace_rows() { return WS_COUNT; }
+#ifdef TMPC_HOST_SIM
+unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
+#endif
 
 size_t block_lds_bytes(int tiles) {
     switch (tiles) {

@@ -109,3 +109,38 @@ def test_edge_cases_and_the_dense_single_shape_under_sanitizers(binaries, oracle
         ok = ref["status"] == 0
         assert np.max(np.abs(o["u_nom"][ok] - ref["u_nom"][ok])) < 1e-8
         assert np.all(np.isnan(o["u_nom"][~ok]))
+
+
+# ---------------------------------------------------------------- the workgroup-per-QP kernel (csrc/tmpc_block.hip)
+@pytest.fixture(scope="module")
+def block_binaries():
+    return {t: run_case.build(t) for t in ("blocksim", "blocksim_asan", "blocksim_msan")}
+
+
+def test_block_kernel_source_under_sanitizers(block_binaries, cartpole, oracle_lib):
+    """solve_block_kernel<1> (256 threads; the cart-pole through the general path) and solve_block_kernel<8> (512 threads, BASELINE
+    config 5: n = 12, m = 4, N = 30, 124 variables) on the host execution model: answers equal the oracle's, ASan / UBSan / MSan
+    report nothing -- the per-workgroup workspace, the LDS and the outputs start out poisoned."""
+    from oracle.oracle import Oracle
+    mpc5, _ = common.make_mpc("synthetic", 30, True, create=False)
+    d5 = mpc5._problem_dict()
+    rng = np.random.default_rng(5)
+    X5 = rng.uniform(-0.5, 0.5, (4, 12)) * mpc5._Xc.b[:12]
+    X5[:2] *= 1.9
+    R5 = np.zeros((4, 12))
+    R5[:, 0] = rng.uniform(-2, 2, 4)
+    idx = np.linspace(0, 599, 16).astype(int)
+    jobs = [("blocksim", cartpole, S[idx, :4], S[idx, 4:]), ("blocksim_asan", cartpole, S[idx[::3], :4], S[idx[::3], 4:]),
+            ("blocksim_msan", cartpole, S[idx[1::3], :4], S[idx[1::3], 4:]), ("blocksim", d5, X5, R5), ("blocksim_asan", d5, X5[:2], R5[:2]),
+            ("blocksim_msan", d5, X5[1:], R5[1:])]
+    with ThreadPoolExecutor(6) as ex:
+        outs = list(ex.map(lambda j: run_case.run(block_binaries[j[0]], j[1], j[2], j[3], env=SAN_ENV, block=True), jobs))
+    nontrivial = 0
+    for (name, d, X, R), o in zip(jobs, outs):
+        assert_clean(o)
+        ref = Oracle(d).solve(X, R)
+        assert np.array_equal(o["status"], ref["status"]) and np.all(o["status"] == 0), (name, o["status"])
+        assert np.max(np.abs(o["u_nom"] - ref["u_nom"])) < 1e-8, name
+        nontrivial += int((o["iters"] > 0).sum())
+        assert o["rendezvous"] > 1000
+    assert nontrivial >= 20

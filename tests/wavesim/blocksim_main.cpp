@@ -1,0 +1,76 @@
+// TEST INFRASTRUCTURE (not product code): csrc/tmpc_block.hip -- the workgroup-per-QP kernel, the source text the GPU build
+// compiles -- on the host execution model of hip_sim.hpp (one fiber per thread of the 256- or 512-thread workgroup), for the
+// sanitizers.  Input: the layout the product library dumps for a host-only handle (tmpc_debug_dump_block_layout) and a batch.
+//
+//   blocksim <layout file> <batch file> <output file>           (formats: wavesim_main.cpp; variant 0 only)
+#include "../../robust-tracking-mpc-over-lossy-networks_amd/csrc/tmpc_block.hip"
+
+#include <cstdio>
+#include <memory>
+#include <vector>
+
+namespace {
+void need(bool ok, const char *what) {
+    if (!ok) { std::fprintf(stderr, "blocksim: %s\n", what); std::exit(2); }
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    need(argc == 4, "usage: blocksim <layout> <batch> <out>");
+    FILE *f = std::fopen(argv[1], "rb");
+    need(f != nullptr, "cannot open layout file");
+    int32_t hd[2];
+    uint64_t sz[2];
+    tmpc::DeviceQP d;
+    tmpc::BlockQP bq;
+    need(std::fread(hd, 4, 2, f) == 2 && std::fread(sz, 8, 2, f) == 2, "short layout file");
+    need(sz[0] == sizeof d && sz[1] == sizeof bq && hd[1] == tmpc::block_workspace_rows(), "layout file written for other structures");
+    need(std::fread(&d, sizeof d, 1, f) == 1 && std::fread(&bq, sizeof bq, 1, f) == 1, "short layout file");
+    const void **fields[] = {reinterpret_cast<const void **>(&d.Hs), reinterpret_cast<const void **>(&d.Hinv), reinterpret_cast<const void **>(&d.F1s),
+                             reinterpret_cast<const void **>(&d.F2s), reinterpret_cast<const void **>(&d.gp0), reinterpret_cast<const void **>(&d.Ep),
+                             reinterpret_cast<const void **>(&d.Dv), reinterpret_cast<const void **>(&d.Tzs), reinterpret_cast<const void **>(&d.Txf),
+                             reinterpret_cast<const void **>(&d.Mth), reinterpret_cast<const void **>(&d.A), reinterpret_cast<const void **>(&d.B),
+                             reinterpret_cast<const void **>(&bq.Grm), reinterpret_cast<const void **>(&bq.Gcm), reinterpret_cast<const void **>(&bq.GHrm),
+                             reinterpret_cast<const void **>(&bq.g0), reinterpret_cast<const void **>(&bq.Es), reinterpret_cast<const void **>(&bq.ncols)};
+    std::vector<std::unique_ptr<char[]>> keep;
+    for (const void **fp : fields) {
+        uint64_t n;
+        need(std::fread(&n, 8, 1, f) == 1, "short layout file");
+        if (n == 0) { *fp = nullptr; continue; }
+        keep.emplace_back(new char[n]);
+        need(std::fread(keep.back().get(), 1, n, f) == n, "short layout file");
+        *fp = keep.back().get();
+    }
+    std::fclose(f);
+    d.dbg = nullptr; d.save = nullptr; d.ticks = nullptr;
+    d.Gt = d.Hct = d.Psi = d.g0p = d.Esp = nullptr; d.vmask = nullptr; d.row_of = nullptr;
+
+    f = std::fopen(argv[2], "rb");
+    need(f != nullptr, "cannot open batch file");
+    int64_t B, nx, has_var;
+    need(std::fread(&B, 8, 1, f) == 1 && std::fread(&nx, 8, 1, f) == 1 && nx == d.nx && B >= 0, "bad batch file");
+    std::vector<double> xk(static_cast<size_t>(B * nx)), ref(xk.size());
+    need(std::fread(xk.data(), 8, xk.size(), f) == xk.size() && std::fread(ref.data(), 8, ref.size(), f) == ref.size(), "short batch file");
+    need(std::fread(&has_var, 8, 1, f) == 1 && !has_var, "variant 0 only");
+    std::fclose(f);
+
+    const int N = d.N, nu = d.nu;
+    const size_t b = static_cast<size_t>(B);
+    std::unique_ptr<double[]> u(new double[b * N * nu]), x0(new double[b * nx]), ss(new double[b * (nx + nu)]);
+    std::unique_ptr<int32_t[]> st(new int32_t[b]), it(new int32_t[b]);
+    // the per-workgroup workspace: uninitialised on purpose
+    std::unique_ptr<double[]> ws(new double[static_cast<size_t>(tmpc::block_workspace_rows()) * bq.ncp]);
+    const hipError_t e = tmpc::launch_block(d, bq, hd[0], ws.get(), 1, 0, B, xk.data(), ref.data(), nullptr, u.get(), x0.get(), ss.get(), nullptr,
+                                           st.get(), it.get(), nullptr);
+    need(e == hipSuccess, "launch failed");
+    std::fprintf(stderr, "blocksim: tmpc::solve_block_kernel<%d>, %lld instances\n", hd[0], static_cast<long long>(B));
+    FILE *o = std::fopen(argv[3], "wb");
+    need(o != nullptr, "cannot open output file");
+    need(std::fwrite(u.get(), 8, b * N * nu, o) == b * N * nu && std::fwrite(x0.get(), 8, b * nx, o) == b * nx &&
+         std::fwrite(ss.get(), 8, b * (nx + nu), o) == b * (nx + nu) && std::fwrite(st.get(), 4, b, o) == b && std::fwrite(it.get(), 4, b, o) == b,
+         "short write");
+    const uint64_t nr = tmpc::sim_rendezvous_count();
+    std::fwrite(&nr, 8, 1, o);
+    std::fclose(o);
+    return 0;
+}

@@ -17,17 +17,19 @@ def build(target="wavesim", extra=""):
     return os.path.join(BUILD, target)
 
 
-def run(binary, d, X, R, variant=None, env=None, timeout=1800):
+def run(binary, d, X, R, variant=None, env=None, timeout=1800, block=False):
+    """block: the workgroup-per-QP kernel (blocksim binaries, variant 0 only)"""
     from LinearMPCOverNetworks import _native
     L = _native.lib()
-    L.tmpc_debug_dump_layout.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    dump = L.tmpc_debug_dump_block_layout if block else L.tmpc_debug_dump_layout
+    dump.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
     h = _native.create(d, -1)
     try:
         with tempfile.TemporaryDirectory() as tmp:
             lays = []
             for k in range(2 if variant is not None else 1):
                 path = os.path.join(tmp, f"layout{k}.bin")
-                rc = L.tmpc_debug_dump_layout(h.ptr, k, path.encode())
+                rc = dump(h.ptr, k, path.encode())
                 if rc != 0:
                     raise RuntimeError(f"tmpc_debug_dump_layout({k}) failed: {rc}")
                 lays.append(path)
