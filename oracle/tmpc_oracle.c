@@ -467,7 +467,8 @@ static int polish(const form_t *f, work_t *w) {
     const double *Gs = f->Gs, *Hs = f->Hs, *Hinv = f->Hinv;
     for (int i = 0; i < nc; ++i) { w->inW[i] = w->lam[i] > w->s[i]; w->yall[i] = w->lam[i]; }
     memcpy(w->zp, w->z, sizeof(double) * nv);
-    for (int it = 0; it < 6; ++it) {
+    int loose_retries = 0;      /* rounds that only repeat the Newton steps on an unchanged working set (see below) */
+    for (int it = 0; it < 6 + loose_retries; ++it) {
         ++g_polish_rounds;
         int m = 0;
         for (int i = 0; i < nc; ++i) if (w->inW[i]) { if (m >= w->wcap) return 0; w->W[m++] = i; }
@@ -492,7 +493,7 @@ static int polish(const form_t *f, work_t *w) {
             for (int a = 0; a < m; ++a) w->S[a * m + a] += 1e-11 * dmax;
             if (chol(w->S, m)) return 0;
             for (int k = 0; k < m; ++k) w->y[k] = w->yall[w->W[k]];
-            for (int step = 0; step < 4; ++step) {
+            for (int step = 0; step < (loose_retries ? 12 : 4); ++step) {
                 for (int i = 0; i < nv; ++i) {           /* r1 = Hs z + q + G_W' y */
                     double v = w->q[i];
                     for (int j = 0; j < nv; ++j) v += Hs[i * nv + j] * w->zp[j];
@@ -535,7 +536,15 @@ static int polish(const form_t *f, work_t *w) {
         if (getenv("ORACLE_DEBUG")) fprintf(stderr, "   polish it %d m %d nviol %d nneg %d nloose %d\n", it, m, nviol, nneg, nloose);
         /* rows of W off their bound with nothing left to correct: the steps have not converged, give up.
          * (With wrong rows still in W the system is inconsistent and looseness is expected: correct W first.) */
-        if (nloose && nviol == 0 && nneg == 0) return 0;
+        if (nloose && nviol == 0 && nneg == 0) {
+            /* Nearly parallel working rows (neighbouring facets of the 854-row initial-state set, both active): S is nearly
+             * singular along their difference and the proximal steps contract that component slowly, although z no longer
+             * moves.  The working set is right: the same set gets up to two more rounds of twelve steps before giving up. */
+            if (loose_retries >= 2) return 0;
+            ++loose_retries;
+            for (int k = 0; k < m; ++k) w->yall[w->W[k]] = w->y[k];
+            continue;
+        }
         if (nviol == 0 && nneg == 0) {
             memcpy(w->z, w->zp, sizeof(double) * nv);
             for (int i = 0; i < nc; ++i) { w->lam[i] = 0; w->s[i] = w->r[i] < 0 ? -w->r[i] : 0; }
@@ -635,7 +644,12 @@ static int solve_dense(const form_t *f, const double *xk, const double *ref, dou
             }
             try_tol *= 1e-2;
         }
-        if (gap <= 1e-15 * objs) { status = TMPC_STATUS_MAX_ITER; break; }   /* nothing left to gain */
+        if (gap <= 1e-15 * objs) {
+            /* nothing left to gain from further iterations (the dual residual stalls on the ill-conditioned systems of such
+             * a small mu and keeps the hand-over test above from passing): the refinement gets this iterate as it is */
+            status = polish(f, w) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER;
+            break;
+        }
         /* Farkas-type infeasibility test: lam blows up while G'lam -> 0 and h'lam < 0 */
         if (lmax > 1e10) {
             double hl = 0, gn = 0;

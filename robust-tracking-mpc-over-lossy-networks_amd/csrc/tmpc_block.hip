@@ -823,6 +823,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
             const double ncd = static_cast<double>(nc);
             int it = 0;
             double rdn_last = 0.0;
+            bool floor_tried = false;
             for (;;) {
                 bool want_polish = false;
                 for (; it < qp.max_iter; ++it) {
@@ -865,7 +866,12 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     const double objs = fmax(fabs(obj), 1.0);
                     const bool try_polish = (rdn <= 1e3 * try_tol * qn) && (rpn <= try_tol * hn) && (gap <= try_tol * objs);
                     if (try_polish) { want_polish = true; rdn_last = rdn; break; }
-                    if (gap <= 1e-15 * objs) { st = TMPC_STATUS_MAX_ITER; break; }
+                    if (gap <= 1e-15 * objs) {
+                        // (stalled gap: the refinement gets this iterate as it is, once -- tmpc_kernels.hip)
+                        st = TMPC_STATUS_MAX_ITER;
+                        if (!floor_tried) { floor_tried = true; want_polish = true; rdn_last = INFINITY; }
+                        break;
+                    }
                     if (lmax > 1e10) {
                         double hl = 0.0;
                         for (int r = tid; r < nc; r += BT) hl += h_[r] * lam_[r];
@@ -994,7 +1000,8 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         yall_[r] = lv;
                     }
                     if (tid < NVP) zpv[tid] = zv[tid];
-                    for (int round = 0; round < 6 && !ok; ++round) {
+                    int loose_retries = 0;        // rounds that only repeat the Newton steps on an unchanged working set (tmpc_kernels.hip)
+                    for (int round = 0; round < 6 + loose_retries && !ok; ++round) {
                         __syncthreads();
                         if (wave == 0) {
                             int m0 = 0;
@@ -1073,7 +1080,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                                 block_reduce3<SH::BW, OpMax, OpMax, OpMax>(dzl, zl, dum, red, wave, lane);
                                 if (stp >= 1) {       // the step no longer moves the iterate, or what is left after it cannot (tmpc_kernels.hip)
                                     const double rho = dzl / fmax(dz_prev, 1e-300);
-                                    if (dzl <= 1e-14 * zl || (rho < 0.5 && dzl * rho <= 0.5e-15 * zl)) break;
+                                    if (dzl <= 1e-14 * zl || (loose_retries == 0 && rho < 0.5 && dzl * rho <= 0.5e-15 * zl)) break;
                                 }
                                 dz_prev = dzl;
                             }
@@ -1109,7 +1116,11 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         }
                         block_reduce3<SH::BW, OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
                         // rows of W off their bound with nothing left to correct: not converged, give up (see tmpc_kernels.hip)
-                        if (nloose != 0.0 && nviol == 0.0 && nneg == 0.0) break;
+                        if (nloose != 0.0 && nviol == 0.0 && nneg == 0.0) {
+                            if (loose_retries >= 2) break;
+                            ++loose_retries;          // the set is right, its nearly parallel rows need more steps
+                            continue;
+                        }
                         if (nviol == 0.0 && nneg == 0.0) {
                             ok = true;
                             if (tid < NVP) zv[tid] = zpv[tid];

@@ -1,0 +1,148 @@
+"""BASELINE.json's configurations 3 and 5 at their FULL batch sizes (65536 and 16384): too many instances for the oracle, so
+the whole batch is checked through size-independent properties of the problem -- every status is a verdict, certified optima
+satisfy the constraints the reference states (input box, initial-state set of the packet-received problem, dynamics), a
+permuted batch gives the permuted answer, repeated launches are bit-identical -- and a sample goes to the oracle and to the
+exact distance-to-minimiser certificate (oracle/qp_sparse.py).  GPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+from oracle import qp_sparse
+from oracle.oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+OUT = os.path.join(os.path.dirname(common.PKG), "gpurun_out")
+
+
+def test_config3_extended_gamma_mix_at_65536(hip_lib, oracle_lib):
+    """Cart-pole N = 20 (results_linear_system.py:64), ExtendedTubeTrackingMPC: (x_hat, ref, gamma) of extended closed loops
+    (what bench.py's config3 solves), both problems in one call: solve_kernel<24,2,0,5,4,0> and solve_kernel<28,2,0,4,7,0>."""
+    from LinearMPCOverNetworks import workloads
+    mpc, w = workloads.make_controller("cartpole", 20, True, extended=True, device=0)
+    assert mpc.get_kernel_path(0) == "wave" and mpc.get_kernel_path(1) == "wave"
+    X0, R0, G0 = workloads.harvest_closed_loop_states(mpc, w, 512, 32, seed=300, extended=True)
+    reps = 65536 // len(X0)
+    rng = np.random.default_rng(33)
+    X, R, G = np.tile(X0, (reps, 1)), np.tile(R0, (reps, 1)), np.tile(G0, reps)
+    X[len(X0):] += rng.uniform(-1, 1, X[len(X0):].shape) * 0.25 * w["w_bound"]       # the copies are perturbed: 65536 distinct instances
+    perm = rng.permutation(len(X))
+    X, R, G = X[perm], R[perm], G[perm]
+    B = len(X)
+    assert B == 65536 and 0.5 < G.mean() < 0.9
+    out = mpc._solve(X, R, G, want_traj=True)
+    st = out["status"]
+    odd = np.flatnonzero((st != 0) & (st != 2))
+    if len(odd):                                                   # kept for inspection (gpurun merges gpurun_out/ back)
+        os.makedirs(OUT, exist_ok=True)
+        np.save(os.path.join(OUT, "config3_uncertified.npy"), np.c_[X[odd], R[odd], G[odd], st[odd], out["iters"][odd]])
+    assert np.all((st >= 0) & (st <= 2)), np.bincount(st)
+    assert len(odd) <= 2, (len(odd), X[odd[:4]], R[odd[:4]], G[odd[:4]])       # an uncertified iterate is an event worth a fixture
+    good = st == 0
+    assert good.mean() > 0.99
+    p = mpc._problem_dict()
+    u, xn = out["u_nom"][good], out["x_nom"][good]
+    assert np.all(np.abs(u) <= np.asarray(p["hu"]).max() + 1e-9)                     # tightened input box (TubeTrackingMPC.py:110)
+    A, Bm = np.asarray(p["A"]), np.asarray(p["B"])
+    dyn = xn[:, 1:] - (xn[:, :-1] @ A.T + u @ Bm.T)
+    assert np.max(np.abs(dyn)) < 1e-9                                                 # TubeTrackingMPC.py:138
+    Hx, hx = np.asarray(p["Hx"]), np.asarray(p["hx"])
+    assert np.max(xn[:, :-1] @ Hx.T - hx) < 1e-8                                      # :139
+    g1 = G[good] == 1
+    HZW, hZW = np.asarray(p["HZW"]), np.asarray(p["hZW"])
+    assert np.max((X[good][g1] - xn[g1, 0]) @ HZW.T - hZW) < 1e-8                     # :278 (packet-received problem)
+    assert np.max(np.abs(xn[~g1, 0] - X[good][~g1])) < 1e-12                          # :127 (fixed initial state)
+    again = mpc._solve(X, R, G, want_traj=False)
+    assert np.array_equal(again["status"], st) and np.array_equal(again["u_nom"][good], out["u_nom"][good])     # bit-identical
+    pm = rng.permutation(B)
+    moved = mpc._solve(X[pm], R[pm], G[pm], want_traj=False)
+    assert np.array_equal(moved["status"], st[pm])
+    np.testing.assert_allclose(moved["u_nom"][good[pm]], out["u_nom"][pm][good[pm]], rtol=0, atol=1e-9)
+    sub = rng.choice(B, 1536, replace=False)
+    ref = Oracle(p).solve(X[sub], R[sub], G[sub])
+    assert np.array_equal(st[sub] == 2, ref["status"] == 2)
+    ok = (st[sub] == 0) & (ref["status"] == 0)
+    assert ok.sum() > 1400
+    np.testing.assert_allclose(out["u_nom"][sub][ok], ref["u_nom"][ok], rtol=0, atol=1e-8)
+    tpl = {v: qp_sparse.SparseTemplate(p, v) for v in (0, 1)}
+    worst = 0.0
+    for k in sub[:96]:
+        if st[k] != 0:
+            continue
+        qp = tpl[int(G[k])].instance(X[k], R[k])
+        v = qp_sparse.pack(qp, out["x_nom"][k], out["u_nom"][k], out["x_ss"][k], out["u_ss"][k])
+        d = qp_sparse.minimiser_distance(qp, v)
+        assert d["certified"] and d["du0"] <= 1e-8, (k, d["du0"], d["certified"])
+        worst = max(worst, d["du0"])
+    print(f"config 3 at {B}: {good.sum()} optimal, {int((st == 2).sum())} infeasible, {len(odd)} uncertified; "
+          f"worst distance of u_0 from the exact minimiser on a sample of 96: {worst:.2e}")
+
+
+def test_config5_at_16384(hip_lib, oracle_lib):
+    """Synthetic n = 12, m = 4, N = 30 (124 variables, 1236 rows): solve_block_kernel<8> on the full batch of BASELINE configs[4]."""
+    from LinearMPCOverNetworks import workloads
+    mpc, w = workloads.make_controller("synthetic", 30, True, device=0)
+    assert mpc.get_kernel_path() == "block"
+    rng = np.random.default_rng(50)
+    B = 16384
+    X = rng.uniform(-0.5, 0.5, (B, 12)) * mpc._Xc.b[:12]
+    X[: B // 8] *= 1.9                                  # an eighth of the batch close to / beyond the boundary of the tightened set
+    R = np.zeros((B, 12))
+    R[:, 0] = rng.uniform(-2, 2, B)
+    out = mpc._solve(X, R, want_traj=True)
+    st = out["status"]
+    assert np.all((st == 0) | (st == 2)), np.bincount(st)
+    good = st == 0
+    assert good.mean() > 0.9 and (out["iters"][good] > 0).mean() > 0.5
+    p = mpc._problem_dict()
+    u, xn = out["u_nom"][good], out["x_nom"][good]
+    Hu, hu = np.asarray(p["Hu"]), np.asarray(p["hu"])
+    assert np.max(u.reshape(-1, 4) @ Hu.T - hu) < 1e-9
+    A, Bm = np.asarray(p["A"]), np.asarray(p["B"])
+    assert np.max(np.abs(xn[:, 1:] - (xn[:, :-1] @ A.T + u @ Bm.T))) < 1e-9
+    Hx, hx = np.asarray(p["Hx"]), np.asarray(p["hx"])
+    assert np.max(xn[:, :-1] @ Hx.T - hx) < 1e-8
+    HT, hT = np.asarray(p["HT"]), np.asarray(p["hT"])
+    term = np.c_[xn[:, -1], out["x_ss"][good], out["u_ss"][good]] @ HT.T - hT
+    assert np.max(term) < 1e-8                                                        # TubeTrackingMPC.py:149
+    assert np.max(np.abs(out["x_ss"][good] @ (A - np.eye(12)).T + out["u_ss"][good] @ Bm.T)) < 1e-9      # :147
+    again = mpc._solve(X, R, want_traj=False)
+    assert np.array_equal(again["status"], st) and np.array_equal(again["u_nom"][good], out["u_nom"][good])
+    pm = rng.permutation(B)
+    moved = mpc._solve(X[pm], R[pm], want_traj=False)
+    assert np.array_equal(moved["status"], st[pm])
+    np.testing.assert_allclose(moved["u_nom"][good[pm]], out["u_nom"][pm][good[pm]], rtol=0, atol=1e-9)
+    sub = rng.choice(B, 384, replace=False)
+    ref = Oracle(p).solve(X[sub], R[sub])
+    assert np.array_equal(st[sub], ref["status"])
+    ok = ref["status"] == 0
+    np.testing.assert_allclose(out["u_nom"][sub][ok], ref["u_nom"][ok], rtol=0, atol=1e-8)
+    tpl = qp_sparse.SparseTemplate(p, 0)
+    for k in sub[:24]:
+        if st[k] != 0:
+            continue
+        qp = tpl.instance(X[k], R[k])
+        v = qp_sparse.pack(qp, out["x_nom"][k], out["u_nom"][k], out["x_ss"][k], out["u_ss"][k])
+        d = qp_sparse.minimiser_distance(qp, v)
+        assert d["certified"] and d["du0"] <= 1e-8, (k, d["du0"], d["certified"])
+
+
+def test_hard_packet_received_states_certify_on_the_device(hip_lib, oracle_lib):
+    """The eleven degenerate instances of tests/golden/cartpole_N20_extended_hard_states.npy (see tests/test_oracle.py): every
+    one certified on the device, equal to the oracle, within 1e-8 of the exact minimiser."""
+    from LinearMPCOverNetworks import workloads
+    D = np.load(os.path.join(common.GOLDEN, "cartpole_N20_extended_hard_states.npy"))
+    X, R, G = np.ascontiguousarray(D[:, :4]), np.ascontiguousarray(D[:, 4:8]), D[:, 8].astype(np.uint8)
+    mpc, w = workloads.make_controller("cartpole", 20, True, extended=True, device=0)
+    out = mpc._solve(X, R, G, want_traj=True)
+    assert np.all(out["status"] == 0), out["status"]
+    p = mpc._problem_dict()
+    ref = Oracle(p).solve(X, R, G)
+    np.testing.assert_allclose(out["u_nom"], ref["u_nom"], rtol=0, atol=1e-8)
+    tpl = {v: qp_sparse.SparseTemplate(p, v) for v in (0, 1)}
+    for k in range(len(X)):
+        qp = tpl[int(G[k])].instance(X[k], R[k])
+        v = qp_sparse.pack(qp, out["x_nom"][k], out["u_nom"][k], out["x_ss"][k], out["u_ss"][k])
+        d = qp_sparse.minimiser_distance(qp, v)
+        assert d["certified"] and d["du0"] <= 1e-8, (k, d["du0"])

@@ -228,3 +228,29 @@ def test_minimiser_distance_measures_u0_shift():
     d2 = qp_sparse.minimiser_distance(qp, v2)
     assert c2["r_stat"] < 1e-7                    # the residual certificate does not see it
     assert d2["certified"] and abs(d2["du0"] - 1e-6) < 1e-8, d2["du0"]      # the distance does
+
+
+def test_hard_packet_received_states_certify(oracle_lib):
+    """tests/golden/cartpole_N20_extended_hard_states.npy: the eleven instances (x_hat, ref, gamma) of a 65536-instance
+    extended closed-loop batch at N = 20 (tests/test_full_size.py wrote them out) that round 2's refinement left uncertified
+    (TMPC_STATUS_MAX_ITER with the exact minimiser in hand): degenerate vertices of the packet-received problem with
+    nearly parallel active facets of the 854-row initial-state set.  With the repeated Newton steps on an unchanged working
+    set and the refinement at the stalled-gap exit they certify; the exact distance certificate agrees."""
+    import os
+    import common
+    from LinearMPCOverNetworks import polytope_lite
+    from oracle import qp_sparse
+    from oracle.oracle import Oracle
+    D = np.load(os.path.join(common.GOLDEN, "cartpole_N20_extended_hard_states.npy"))
+    X, R, G = D[:, :4], D[:, 4:8], D[:, 8].astype(np.uint8)
+    mpc, _ = common.make_mpc("cartpole", 20, True, extended=True, create=False)
+    polytope_lite.set_lp_backend("scipy")
+    p = mpc._problem_dict()
+    o = Oracle(p).solve(X, R, G)
+    assert np.all(o["status"] == 0), o["status"]
+    tpl = {v: qp_sparse.SparseTemplate(p, v) for v in (0, 1)}
+    for k in range(len(X)):
+        qp = tpl[int(G[k])].instance(X[k], R[k])
+        v = qp_sparse.pack(qp, o["x_nom"][k], o["u_nom"][k], o["x_ss"][k], o["u_ss"][k])
+        d = qp_sparse.minimiser_distance(qp, v)
+        assert d["certified"] and d["du0"] < 1e-9, (k, d["du0"])

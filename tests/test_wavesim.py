@@ -32,7 +32,7 @@ CLEAN_MARKERS = ("ERROR: AddressSanitizer", "runtime error:", "WARNING: MemorySa
 @pytest.fixture(scope="module")
 def binaries():
     # (also built by __graft_entry__.build(); make leaves them alone when they are up to date)
-    return {t: run_case.build(t, "-DTMPC_SIM_SHAPES") for t in ("wavesim", "wavesim_asan", "wavesim_msan")}
+    return run_case.build_all()
 
 
 @pytest.fixture(scope="module")
@@ -114,7 +114,7 @@ def test_edge_cases_and_the_dense_single_shape_under_sanitizers(binaries, oracle
 # ---------------------------------------------------------------- the workgroup-per-QP kernel (csrc/tmpc_block.hip)
 @pytest.fixture(scope="module")
 def block_binaries():
-    return {t: run_case.build(t) for t in ("blocksim", "blocksim_asan", "blocksim_msan")}
+    return run_case.build_all()
 
 
 def test_block_kernel_source_under_sanitizers(block_binaries, cartpole, oracle_lib):

@@ -12,9 +12,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD = os.path.join(HERE, "_build")
 
 
-def build(target="wavesim", extra=""):
-    subprocess.check_call(["make", "-s", "-C", HERE, f"_build/{target}"] + ([f"EXTRA={extra}"] if extra else []))
-    return os.path.join(BUILD, target)
+def build_all(extra="-DTMPC_SIM_SHAPES"):
+    """every binary of the Makefile in one parallel make (what __graft_entry__.build() runs as well); up to date -> no-op"""
+    subprocess.check_call(["make", "-s", "-j6", "-C", HERE, "all", f"EXTRA={extra}"])
+    return {t: os.path.join(BUILD, t) for t in ("wavesim", "wavesim_asan", "wavesim_msan", "blocksim", "blocksim_asan", "blocksim_msan")}
 
 
 def run(binary, d, X, R, variant=None, env=None, timeout=1800, block=False):
@@ -61,6 +62,7 @@ def run(binary, d, X, R, variant=None, env=None, timeout=1800, block=False):
                      xu_ss=take(B * (nx + nu), np.float64).reshape(B, nx + nu), status=take(B, np.int32), iters=take(B, np.int32))
             o["rendezvous"] = int(take(1, np.uint64)[0])
             o["stderr"] = res.stderr
+            o["stdout"] = res.stdout
             return o
     finally:
         _native.destroy(h)
