@@ -818,6 +818,11 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
     const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
                         8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
+    // what the previous run left in the arena is gone from here on, whether this run gets as far as replacing it or not
+    // (tmpc_mc_get_capture / _solve_ticks / _physics_error must not read a freed or half-written arena)
+    h->mc_cap_dev = nullptr; h->mc_cap_T = 0;
+    h->mc_err2_phys = nullptr; h->mc_phys_B = 0;
+    h->mc_tick_sum = h->mc_tick_max = nullptr; h->mc_tick_B = 0;
     if (need > h->mc_arena_bytes) {
         HIP_TRY(h, hipStreamSynchronize(h->stream));
         if (h->mc_arena) (void)hipFree(h->mc_arena);
