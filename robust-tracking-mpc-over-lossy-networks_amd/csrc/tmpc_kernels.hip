@@ -180,8 +180,10 @@ struct Shape {
     static constexpr int WCAP = NV_ <= 24 ? 24 : 28;              // max rows in the refinement's working set (<= WS_CAP)
     // row strides of the small LDS matrices that are read with the row on the lane (Hs, Hs^-1, the expanded working rows;
     // T = Hs^-1 G_W'): odd, so that the lanes' rows start in different banks (NV = 24 unpadded: six rows per bank)
-    // (not for NV = 28: that shape's four workspaces fill the LDS to the last kilobyte)
-    static constexpr int LDH = NV_ + (NV_ <= 24 ? 1 : 0), LDT = WCAP + (NV_ <= 24 ? 1 : 0);
+    // (not for NV = 28: that shape's four workspaces fill the LDS to the last kilobyte, and padding Hs / Hs^-1 alone -- which
+    // would still fit at N = 20 -- measured no gain there)
+    static constexpr int LDH = NV_ + (NV_ <= 24 ? 1 : 0);                                         // Hs, Hs^-1
+    static constexpr int LDW = NV_ + (NV_ <= 24 ? 1 : 0), LDT = WCAP + (NV_ <= 24 ? 1 : 0);      // G_W, T
     // dense functionals, row-major in LDS: [FD * 64][LDG]; 16-column blocks of the MFMA tiling cover the NV columns of G
     // plus one more row of the product (row NV of A carries t: see sweep_a_dense); the odd stride keeps both the
     // lane-per-row reads of the sweeps and the 4 x 16 operand reads of the MFMA loop conflict free
@@ -211,7 +213,7 @@ __device__ __forceinline__ void side_info(int i, bool &dense, int &fslot, double
 template <class SH>
 struct WaveLds {
     static constexpr int RED = SH::RR * RED_STRIDE;                                     // transposition tile
-    static constexpr int POL = SH::WCAP * SH::LDH + SH::NV * SH::LDT + 4 * SH::WCAP;              // G_W, T, y, dy, W(idx)
+    static constexpr int POL = SH::WCAP * SH::LDW + SH::NV * SH::LDT + 4 * SH::WCAP;              // G_W, T, y, dy, W(idx)
     static constexpr int MFAC = SH::NV * (SH::NV + 1);                                  // factor of the normal matrix between the two solves (row i at i (NV + 1), then 1 / d_i)
     static constexpr int BIG = RED + MFAC > POL ? RED + MFAC : POL;                     // tile + factor (interior point) and the refinement's workspace are never live together
     static constexpr int SUMS = 2 * SH::NV + 8;                                         // two NV-vectors of G' products
@@ -1089,8 +1091,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             if (!h_valid) { compute_h(); h_valid = true; }
             {
                 // workspace carved from the (now idle) transposition tile
-                double *GW = red;                         // [WCAP][LDH]  rows of the working set, expanded (sign included)
-                double *T = GW + WCAP * SH::LDH;          // [NV][LDT]
+                double *GW = red;                         // [WCAP][LDW]  rows of the working set, expanded (sign included)
+                double *T = GW + WCAP * SH::LDW;          // [NV][LDT]
                 double *yv = T + NV * SH::LDT;            // [WCAP]
                 double *dyv = yv + WCAP;                  // [WCAP]
                 int *Widx = reinterpret_cast<int *>(dyv + WCAP);   // [WCAP] row ids: side * 64 + lane
@@ -1167,7 +1169,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     for (int a = 0; a < KC; ++a) v += Hct[a * NCCP + r] * Psi[a * NV + j];
                                 }
                             }
-                            GW[k * SH::LDH + j] = sgn * v;
+                            GW[k * SH::LDW + j] = sgn * v;
                         }
                         wave_lds_fence();
                         // T = Hinv G_W'  (entry (i,k): i = idx / m, k = idx % m)
@@ -1175,7 +1177,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const int i = idx / m, k = idx - i * m;
                             double v = 0.0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) v += Hinv[i * SH::LDH + j] * GW[k * SH::LDH + j];
+                            for (int j = 0; j < NV; ++j) v += Hinv[i * SH::LDH + j] * GW[k * SH::LDW + j];
                             T[i * SH::LDT + k] = v;
                         }
                         wave_lds_fence();
@@ -1191,7 +1193,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             double gw[NV];
                             const int la = lane < m ? lane : 0;
 #pragma unroll
-                            for (int j = 0; j < NV; ++j) gw[j] = GW[la * SH::LDH + j];
+                            for (int j = 0; j < NV; ++j) gw[j] = GW[la * SH::LDW + j];
                             double sdiag = 0.0;
 #pragma unroll
                             for (int c2 = 0; c2 < MC; ++c2) {
@@ -1221,7 +1223,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 double v = qv[lane];
 #pragma unroll
                                 for (int j = 0; j < NV; ++j) v += Hs[lane * SH::LDH + j] * zpv[j];
-                                for (int k = 0; k < m; ++k) v += GW[k * SH::LDH + lane] * yv[k];
+                                for (int k = 0; k < m; ++k) v += GW[k * SH::LDW + lane] * yv[k];
                                 tv[lane] = v;
                             }
                             wave_lds_fence();
@@ -1238,7 +1240,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             if (lane < m) {
                                 double gz = 0.0, gt = 0.0;
 #pragma unroll
-                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * SH::LDH + j]; gz += g * zpv[j]; gt += g * uv[j]; }
+                                for (int j = 0; j < NV; ++j) { const double g = GW[lane * SH::LDW + j]; gz += g * zpv[j]; gt += g * uv[j]; }
                                 bb = gz - hw[Widx[lane]] - gt;
                             }
                             lanes_forward<MC>(srow, bb, lane);
