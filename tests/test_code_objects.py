@@ -1,0 +1,43 @@
+"""Resource notes of the gfx950 code objects inside lib/libtmpc_hip.so (no GPU needed: the notes are read from the
+library's .hip_fatbin section, scripts/code_object_notes.py).  The wave-per-QP shapes must not touch scratch: builds of that
+kernel with > 120 spilled registers once returned wrong statuses."""
+import importlib.util
+import os
+
+import common
+
+ROOT = os.path.dirname(common.PKG)
+spec = importlib.util.spec_from_file_location("code_object_notes", os.path.join(ROOT, "scripts", "code_object_notes.py"))
+notes = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(notes)
+
+
+def _kernels():
+    ks = notes.kernels(os.path.join(common.PKG, "lib", "libtmpc_hip.so"))
+    dm = notes.demangle(list(ks))
+    return {dm[n]: k for n, k in ks.items()}
+
+
+def test_wave_shapes_have_no_private_segment():
+    ks = _kernels()
+    wave = {n: k for n, k in ks.items() if "::solve_kernel<" in n}
+    assert len(wave) == 10, sorted(wave)
+    for n, k in wave.items():
+        assert k[".private_segment_fixed_size"] == 0, (n, k[".private_segment_fixed_size"], k[".vgpr_spill_count"])
+        # (a spill count without a private segment is the accumulation-register file used as spill space: NV = 28)
+        assert k[".vgpr_spill_count"] <= 16, (n, k[".vgpr_spill_count"])
+    bench = [k for n, k in wave.items() if "solve_kernel<12, 1, 0, 5, 4, 0, 8>" in n]
+    assert len(bench) == 1 and bench[0][".vgpr_count"] <= 256 and bench[0][".vgpr_spill_count"] == 0      # two waves per SIMD
+
+
+def test_other_kernels_stay_within_their_known_footprint():
+    """The block kernel's scratch is call-boundary traffic of wave-uniform values; this keeps it from growing
+    unnoticed.  The LP kernels and the closed-loop kernels: the LP shapes carry none."""
+    ks = _kernels()
+    block = {n: k for n, k in ks.items() if "::solve_block_kernel<" in n}
+    assert len(block) == 4
+    for n, k in block.items():
+        assert k[".vgpr_spill_count"] <= 96 and k[".private_segment_fixed_size"] <= 512, (n, k[".vgpr_spill_count"], k[".private_segment_fixed_size"])
+    for n, k in ks.items():
+        if "::lp_kernel<" in n:
+            assert k[".private_segment_fixed_size"] == 0, n
