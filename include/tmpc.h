@@ -28,7 +28,7 @@ extern "C" {
 /* 1: first cut; 2: projected terminal rows of the packet-received problem (HTP, hTP, rTP); 3: tmpc_lp_batch, TMPC_STATUS_UNBOUNDED;
  * 4: terminal_equality, tmpc_kernel_name; 5: an iterate that hits the iteration cap keeps TMPC_STATUS_MAX_ITER whatever its
  * constraint violation (INFEASIBLE only with a Farkas-type certificate), host-only handles report their kernel path,
- * tmpc_debug_dump_layout */
+ * tmpc_debug_dump_layout (tmpc_debug_dump_lp_layout was added later without a bump: a new export, nothing else changed) */
 #define TMPC_ABI_VERSION 5
 
 /* error codes (function return values) */
@@ -198,6 +198,10 @@ int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path);
  * tmpc::BlockQP (uint64 x 2), the two structures, then the arrays Hs, Hinv, F1s, F2s, gp0, Ep, Dv, Tzs, Txf, Mth, A, B of the
  * first and Grm, Gcm, GHrm, g0, Es, ncols of the second, each as a uint64 byte count and the bytes. */
 int tmpc_debug_dump_block_layout(const tmpc_handle *h, int variant, const char *path);
+/* The same for the batched LP kernel (tmpc_lp_batch): the polytope (H, h) in kernel units -- int32 d, nr, nrp, DP (padded
+ * dimension), max_iter; double tol, relax_by, hm; then H transposed [DP][nrp], h [nrp] and the row scale [nrp].  No device
+ * is touched.  TMPC_E_INVALID when the batch would be decided on the host (no normal at all, or a row 0 <= h_r < 0). */
+int tmpc_debug_dump_lp_layout(int32_t d, int32_t nr, const double *H, const double *h, double relax_by, const char *path);
 
 /*
  * Device-resident closed loop over a lossy network for B independent trajectories and T time steps: the body
@@ -357,8 +361,11 @@ int tmpc_get_condensed(const tmpc_handle *h, int variant,
  *           by relax_by IN THE UNITS OF h AS PASSED (the redundancy test of row i is
  *           "maximise H[i,:] x with h[i] + 1", polytope.reduce)
  *   val     B        x   B x d maximiser or NULL
- *   status  B  TMPC_STATUS_* (OPTIMAL: vertex-exact or converged to 1e-9; MAX_ITER: last
- *           iterate, accurate to about 1e-8; INFEASIBLE; UNBOUNDED: val = +inf)
+ *   status  B  TMPC_STATUS_* (OPTIMAL: x feasible to 1e-11 max(|h_r|, 1), with multipliers
+ *           y >= -1e-10 max(y) on active rows and |c - H'y|_inf <= 1e-11 |c| -- a point of
+ *           the optimal face, or the interior-point iterate at gap 1e-12 and the same dual
+ *           residual; MAX_ITER: last iterate without that certificate, accurate to about
+ *           1e-8; INFEASIBLE; UNBOUNDED: val = +inf)
  *   iters   B  interior-point iterations
  * All pointers are HOST pointers (this is a set-up step; the data is small).  Errors:
  * negative TMPC_E_* code, text through tmpc_last_error(NULL).

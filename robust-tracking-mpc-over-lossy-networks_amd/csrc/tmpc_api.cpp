@@ -1022,24 +1022,25 @@ int tmpc_get_condensed(const tmpc_handle *h, int variant, double *H, double *F1,
         }                                                                                  \
     } while (0)
 
-int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const double *hv, int64_t B, const double *C,
-                  const int32_t *relax, double relax_by, double *val, double *x, int32_t *status, int32_t *iters) {
-    if (!H || !hv || (B > 0 && (!C || !val || !status || !iters)) || B < 0) {
-        g_create_error = "tmpc_lp_batch: NULL argument";
-        return TMPC_E_INVALID;
-    }
-    const int DP = tmpc::lp_padded_dim(d);
-    if (d < 1 || DP < 0 || nr < 1) {
+namespace {
+// the polytope in kernel units: rows to unit norm, h to max |h| = 1 (one scalar: x scales with it, the directions do not)
+struct LpHost {
+    int DP = 0, nrp = 0;
+    double hm = 1.0;
+    bool empty_set = false, no_normal = false;
+    std::vector<double> Ht, hs, rs;
+};
+
+int lp_prepare(int32_t d, int32_t nr, const double *H, const double *hv, LpHost &o) {
+    o.DP = tmpc::lp_padded_dim(d);
+    if (d < 1 || o.DP < 0 || nr < 1) {
         g_create_error = "tmpc_lp_batch: need 1 <= d <= 32 and nr >= 1";
         return d > 32 ? TMPC_E_UNSUPPORTED : TMPC_E_INVALID;
     }
-    if (relax)
-        for (int64_t b = 0; b < B; ++b)
-            if (relax[b] < -1 || relax[b] >= nr) { g_create_error = "tmpc_lp_batch: relax index out of range"; return TMPC_E_INVALID; }
-    if (B == 0) return TMPC_OK;
-    // rows to unit norm, h to max |h| = 1 (one scalar: x scales with it, the directions do not)
-    const int nrp = (nr + 63) / 64 * 64;
-    std::vector<double> Ht(static_cast<size_t>(DP) * nrp, 0.0), hs(nrp, 1.0), rs(nrp, 0.0);
+    const int nrp = o.nrp = (nr + 63) / 64 * 64;
+    o.Ht.assign(static_cast<size_t>(o.DP) * nrp, 0.0);
+    o.hs.assign(nrp, 1.0);
+    o.rs.assign(nrp, 0.0);
     double hm = 0.0, nmax = 0.0;
     std::vector<double> nrm(nr, 0.0);
     for (int r = 0; r < nr; ++r) {
@@ -1055,31 +1056,58 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     }
     // A row whose normal vanishes against the others (round-off left by a product of matrices) says 0 <= h_r: it
     // constrains nothing, or everything.  Scaling it to unit norm would turn the round-off into a constraint.
-    bool empty_set = false;
     for (int r = 0; r < nr; ++r) {
         if (nrm[r] <= 1e-12 * nmax) {
-            if (hv[r] < -1e-9 * (1.0 + std::fabs(hv[r]))) empty_set = true;
+            if (hv[r] < -1e-9 * (1.0 + std::fabs(hv[r]))) o.empty_set = true;
             continue;                                    // stays as the padding row 0 . x <= 1
         }
-        rs[r] = 1.0 / nrm[r];
-        for (int j = 0; j < d; ++j) Ht[static_cast<size_t>(j) * nrp + r] = H[static_cast<size_t>(r) * d + j] / nrm[r];
-        hs[r] = hv[r] / nrm[r];
-        hm = std::max(hm, std::fabs(hs[r]));
+        o.rs[r] = 1.0 / nrm[r];
+        for (int j = 0; j < d; ++j) o.Ht[static_cast<size_t>(j) * nrp + r] = H[static_cast<size_t>(r) * d + j] / nrm[r];
+        o.hs[r] = hv[r] / nrm[r];
+        hm = std::max(hm, std::fabs(o.hs[r]));
     }
-    if (empty_set || !(nmax > 0.0)) {
+    o.no_normal = !(nmax > 0.0);
+    if (!(hm > 0.0)) hm = 1.0;
+    o.hm = hm;
+    for (int r = 0; r < nr; ++r) {
+        if (o.rs[r] == 0.0) continue;                    // vanishing normal: keeps h = 1 in kernel units
+        o.hs[r] /= hm; o.rs[r] /= hm;
+    }
+    return TMPC_OK;
+}
+
+constexpr int LP_MAX_ITER = 80;
+constexpr double LP_TOL = 1e-8;
+}  // namespace
+
+int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const double *hv, int64_t B, const double *C,
+                  const int32_t *relax, double relax_by, double *val, double *x, int32_t *status, int32_t *iters) {
+    if (!H || !hv || (B > 0 && (!C || !val || !status || !iters)) || B < 0) {
+        g_create_error = "tmpc_lp_batch: NULL argument";
+        return TMPC_E_INVALID;
+    }
+    if (d < 1 || tmpc::lp_padded_dim(d) < 0 || nr < 1) {
+        g_create_error = "tmpc_lp_batch: need 1 <= d <= 32 and nr >= 1";
+        return d > 32 ? TMPC_E_UNSUPPORTED : TMPC_E_INVALID;
+    }
+    if (relax)
+        for (int64_t b = 0; b < B; ++b)
+            if (relax[b] < -1 || relax[b] >= nr) { g_create_error = "tmpc_lp_batch: relax index out of range"; return TMPC_E_INVALID; }
+    if (B == 0) return TMPC_OK;
+    LpHost lh;
+    if (const int rc = lp_prepare(d, nr, H, hv, lh); rc != TMPC_OK) return rc;
+    const int nrp = lh.nrp;
+    const std::vector<double> &Ht = lh.Ht, &hs = lh.hs, &rs = lh.rs;
+    const double hm = lh.hm;
+    if (lh.empty_set || lh.no_normal) {
         // 0 <= h_r < 0 for some r: no point satisfies the rows; no normal at all: every direction is unbounded
         for (int64_t b = 0; b < B; ++b) {
-            val[b] = empty_set ? std::nan("") : INFINITY;
-            status[b] = empty_set ? TMPC_STATUS_INFEASIBLE : TMPC_STATUS_UNBOUNDED;
+            val[b] = lh.empty_set ? std::nan("") : INFINITY;
+            status[b] = lh.empty_set ? TMPC_STATUS_INFEASIBLE : TMPC_STATUS_UNBOUNDED;
             iters[b] = 0;
             if (x) for (int j = 0; j < d; ++j) x[b * d + j] = std::nan("");
         }
         return TMPC_OK;
-    }
-    if (!(hm > 0.0)) hm = 1.0;
-    for (int r = 0; r < nr; ++r) {
-        if (rs[r] == 0.0) continue;                      // vanishing normal: keeps h = 1 in kernel units
-        hs[r] /= hm; rs[r] /= hm;
     }
 
     LP_TRY(hipSetDevice(device));
@@ -1108,8 +1136,8 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     LP_TRY(hipMemcpy(drs, rs.data(), rs.size() * sizeof(double), hipMemcpyHostToDevice));
     LP_TRY(hipMemcpy(dC, C, b * dd * sizeof(double), hipMemcpyHostToDevice));
     tmpc::LpDevice lp{};
-    lp.d = d; lp.nr = nr; lp.nrp = nrp; lp.max_iter = 80;
-    lp.tol = 1e-8; lp.relax_by = relax_by; lp.hm = hm;
+    lp.d = d; lp.nr = nr; lp.nrp = nrp; lp.max_iter = LP_MAX_ITER;
+    lp.tol = LP_TOL; lp.relax_by = relax_by; lp.hm = hm;
     lp.Ht = dHt; lp.h = dh; lp.rscale = drs;
     LP_TRY(tmpc::launch_lp(lp, B, nblocks, dC, drel, dws, dval, dx, dst, dit, nullptr));
     LP_TRY(hipDeviceSynchronize());
@@ -1117,6 +1145,26 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     LP_TRY(hipMemcpy(status, dst, b * sizeof(int32_t), hipMemcpyDeviceToHost));
     LP_TRY(hipMemcpy(iters, dit, b * sizeof(int32_t), hipMemcpyDeviceToHost));
     if (x) LP_TRY(hipMemcpy(x, dx, b * dd * sizeof(double), hipMemcpyDeviceToHost));
+    return TMPC_OK;
+}
+
+// Test support (tests/wavesim): the LP kernel's input in kernel units -- what tmpc_lp_batch uploads -- written to a file.
+// No device is touched.  Format: int32 d, nr, nrp, DP, max_iter; double tol, relax_by, hm; Ht [DP][nrp], h [nrp], rscale [nrp].
+int tmpc_debug_dump_lp_layout(int32_t d, int32_t nr, const double *H, const double *hv, double relax_by, const char *path) {
+    if (!H || !hv || !path) { g_create_error = "tmpc_debug_dump_lp_layout: NULL argument"; return TMPC_E_INVALID; }
+    LpHost lh;
+    if (const int rc = lp_prepare(d, nr, H, hv, lh); rc != TMPC_OK) return rc;
+    if (lh.empty_set || lh.no_normal) { g_create_error = "tmpc_debug_dump_lp_layout: the batch is decided on the host, no kernel input"; return TMPC_E_INVALID; }
+    FILE *f = std::fopen(path, "wb");
+    if (!f) { g_create_error = "tmpc_debug_dump_lp_layout: cannot open the file"; return TMPC_E_INVALID; }
+    const int32_t hd[5] = {d, nr, lh.nrp, lh.DP, LP_MAX_ITER};
+    const double sc[3] = {LP_TOL, relax_by, lh.hm};
+    bool ok = std::fwrite(hd, 4, 5, f) == 5 && std::fwrite(sc, 8, 3, f) == 3;
+    ok = ok && std::fwrite(lh.Ht.data(), 8, lh.Ht.size(), f) == lh.Ht.size();
+    ok = ok && std::fwrite(lh.hs.data(), 8, lh.hs.size(), f) == lh.hs.size();
+    ok = ok && std::fwrite(lh.rs.data(), 8, lh.rs.size(), f) == lh.rs.size();
+    std::fclose(f);
+    if (!ok) { g_create_error = "tmpc_debug_dump_lp_layout: short write"; return TMPC_E_INVALID; }
     return TMPC_OK;
 }
 

@@ -12,14 +12,26 @@
 // the step) lives in a per-wave global workspace that stays in L2, H is stored transposed so that a row sweep is coalesced.
 //
 //   1. Mehrotra predictor-corrector on the normal equations M = H' diag(lam / s) H (d x d, rows of M on the lanes,
-//      LDL' by readlane elimination), infeasible start -- same iteration as the QP kernels without the Hessian.
+//      LDL' by readlane elimination), infeasible start -- same iteration as the QP kernels without the Hessian.  Pivots
+//      that have become round-off are skipped (lp_factor): on an optimal face of dimension >= 1 M loses its rank.
 //   2. Hand-over at tol: the rows with lam > s are the IPM's guess of the optimal face.  A greedy pass keeps the most
 //      active ones that are linearly independent; primal active-set steps then make the answer exact: project onto the face,
 //      multipliers by least squares; a violated row replaces the working row it is (nearly) parallel to, a negative
 //      multiplier leaves, a remaining component of c along the face is followed to the blocking row.  Accept when the
 //      point is feasible, the multipliers are non-negative and c is in the cone of the working rows.
-//   3. Otherwise the IPM continues with a 100 times tighter tolerance and hands over again.
+//   3. Otherwise the IPM continues with a 100 times tighter tolerance and hands over again (1e-8, 1e-10, 1e-12); at
+//      1e-12 its own iterate is accepted if the dual residual is below 1e-11 as well.
+//   4. Otherwise -- c keeps a component along the optimal face that the skipped pivots cannot remove -- the IPM runs on
+//      until the gap has collapsed (the iterate then lies ON its active rows) and feasible ascent directions take over:
+//      non-negative least squares over the active rows gives y >= 0 and p = c - H_A' y with a_j . p <= 0 on all of them,
+//      x moves along p to the first row in the way.  No cycling at degenerate vertices, multipliers non-negative by
+//      construction.  It ends without certificate (status MAX_ITER, the IPM iterate is returned) when |p| ~ 1e-8 has to be
+//      followed over a distance ~1: the round-off of c - H_A' y (1e-16) then decides on which side of an active row x lands.
+#ifdef TMPC_HOST_SIM
+#include "hip_sim.hpp"      // tests/wavesim: this very source compiled for the CPU under sanitizers (never in the product)
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -36,6 +48,10 @@ using namespace wv;
 
 constexpr int LP_WPB = 4;        // waves (= LPs in flight) per workgroup
 constexpr int LP_ARR = 6;        // per-row workspace arrays: s, lam, Hx, w, ds, dlam
+// dual feasibility of an accepted answer, for |c| = 1: multipliers >= -DUAL_TOL_Y max(y), |c - H_W' y|_inf <= DUAL_TOL_P.
+// What c keeps along the face is paid for with the length of the face: on the terminal sets of the synthetic model
+// (d = 28) a residual of 8e-10 left 2e-8 of the value behind.  Primal feasibility: 1e-11 max(|h_r|, 1).
+constexpr double DUAL_TOL_Y = 1e-10, DUAL_TOL_P = 1e-11;
 
 template <int D> __host__ __device__ constexpr int lp_col_off(int j) { return j * D - j * (j - 1) / 2; }
 
@@ -56,6 +72,35 @@ template <> struct LpBlocks<32> { static constexpr int n = 5; static constexpr i
 
 __device__ __forceinline__ double lp_hrow(const LpDevice &p, int rel, int r) {
     return p.h[r] + (r == rel ? p.relax_by * p.rscale[r] : 0.0);
+}
+
+// LDL' of the normal matrix (rows on the lanes, as wv::rows_factor) that SKIPS a pivot lost to cancellation: once the pivot
+// has fallen below piv_tol times the diagonal entry it started from, what is left of it is round-off of the eliminations.
+// On an optimal face of dimension >= 1 (c in the span of fewer than d rows: the usual case for the support functions of
+// a polytope with nearly parallel rows) M = H' diag(lam / s) H loses its rank as the gap closes; dividing by such a pivot
+// sends the step along the face by O(1), and the dual residual picks up eps |M| |dx| per iteration and never comes back.
+// A skipped pivot fixes dx_k = 0 (row and column k leave the system): the iterate stops drifting along the face, whose
+// points are all optimal.
+template <int N>
+__device__ __forceinline__ bool lp_factor(double (&row)[N], double &b, double &dinv, double piv_tol, int lane) {
+    bool ok = true;
+    double diag0 = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) diag0 = (lane == k) ? row[k] : diag0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const double pkk = readlane_d(row[k], k), d0 = readlane_d(diag0, k);
+        ok = ok && (pkk == pkk);
+        const bool skip = !(pkk > piv_tol * d0);
+        const double pinv = skip ? 0.0 : fast_rcp(pkk);
+        const double f = (lane > k) ? row[k] * pinv : 0.0;
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) row[j] = fma(-f, readlane_d(row[j], k), row[j]);
+        b = fma(-f, readlane_d(b, k), b);
+        if (lane > k) row[k] = f;
+        if (lane == k) dinv = pinv;
+    }
+    return ok;
 }
 
 // Columns [J0, J1) of M = H' diag(lam / s) H over this lane's rows, summed over the wave into `sums` (packed lower
@@ -111,6 +156,31 @@ __device__ __forceinline__ void sweep_a(const LpDevice &p, const double *__restr
     }
 }
 
+// The working rows widx[0 .. m) of a face: lane a < m loads row a (gw), all of them go to GW [m][D] in LDS, and
+// S = GW GW' (m x m, identity beyond) is factored with its rows on the lanes.  False: the rows are dependent.
+template <int D>
+__device__ __forceinline__ bool lp_face_factor(const double *__restrict__ Ht, int nrp, const int *widx, int m, double *GW, double (&gw)[D],
+                                               double (&srow)[D], double &sdinv, int lane) {
+    const bool inw = lane < m;
+    const int wr = inw ? widx[lane] : 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        gw[k] = inw ? Ht[static_cast<size_t>(k) * nrp + wr] : 0.0;
+        if (lane < D) GW[lane * D + k] = gw[k];
+    }
+    lds_fence();
+#pragma unroll
+    for (int c2 = 0; c2 < D; ++c2) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) v = fma(gw[k], GW[c2 * D + k], v);
+        srow[c2] = (inw && c2 < m) ? v : ((c2 == lane) ? 1.0 : 0.0);
+    }
+    double bdummy = 0.0;
+    sdinv = 1.0;
+    return rows_factor<D>(srow, bdummy, sdinv, lane);
+}
+
 // STAGED: H' (D x nrp doubles) is copied to LDS once per workgroup and every row sweep reads it from there; otherwise
 // the sweeps read it from global memory (L2)
 template <int D, bool STAGED>
@@ -120,7 +190,11 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                                                               int32_t *__restrict__ status, int32_t *__restrict__ iters) {
     using L = LpLds<D>;
     constexpr int NT = L::NT;
+#ifdef TMPC_HOST_SIM
+    double *smem = sim::lds<double>();
+#else
     extern __shared__ __attribute__((aligned(16))) double smem[];
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double *red = smem + wave * L::TOTAL;
     double *sums = red + L::RED;
@@ -173,10 +247,10 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
         int st = TMPC_STATUS_MAX_ITER, it = 0;
         double try_tol = p.tol, rdn_last = 0.0;
         double value = NAN;
-        bool from_polish = false;
+        bool from_polish = false, collapse = false;
 
         for (;;) {
-            bool want_polish = false;
+            bool want_polish = false, stalled = false;
             for (; it < p.max_iter; ++it) {
                 // ---- pass A: residuals, M = H' D H, H'(d.rp), H'lam (for d > 16 the lower triangle of M is accumulated
                 // in column blocks, one sweep over the rows each, to stay inside the register file)
@@ -197,7 +271,13 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                 rdn_last = rdn;
                 if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
                 const double objs = fmax(fabs(obj), 1.0);
-                if (rdn <= 1e3 * try_tol && rpn <= try_tol * hn && gap <= try_tol * objs) { want_polish = true; break; }
+#ifdef TMPC_LP_DEBUG
+                if (lane == 0) printf("lp %lld it %d rdn %.3e rpn %.3e gap %.3e obj %.12e tol %.1e lmax %.2e\n", (long long)b, it, rdn, rpn, gap, obj, try_tol, lmax);
+#endif
+                if (!collapse && rdn <= 1e3 * try_tol && rpn <= try_tol * hn && gap <= try_tol * objs) { want_polish = true; break; }
+                // the gap has collapsed and the dual residual has not followed: what is left of it lies along directions of the
+                // optimal face that the factorisation cannot resolve any more (lp_factor); only vertex steps can remove it
+                if (rpn <= try_tol * hn && gap <= 1e-6 * try_tol * objs) { want_polish = stalled = true; break; }
                 if (xn > 1e9) { st = TMPC_STATUS_UNBOUNDED; break; }
                 if (lmax > 1e10) {
                     double hl = 0.0;
@@ -205,28 +285,28 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                     hl = wave_reduce<OpSum>(hl);
                     if (hl < 0.0) { st = TMPC_STATUS_INFEASIBLE; break; }
                 }
-                // ---- factor M, predictor.  No regularisation unless a pivot fails: near the solution the weak directions
-                // of M carry the dual residual, a shift large enough to matter for the pivots would freeze them
+                // ---- factor M, predictor.  No regularisation: near the solution the weak directions of M carry the dual
+                // residual, a shift large enough to matter for the pivots would freeze them; pivots that are round-off are
+                // skipped instead (lp_factor)
                 double mrow[D], mdinv = 1.0;
-                double trc = 0.0;
-#pragma unroll
-                for (int j = 0; j < D; ++j) trc += sums[lp_col_off<D>(j)];
                 const double rhs_i = lane < D ? cv[lane] - sums[NT + lane] : 0.0;
                 double bb = rhs_i;
                 bool spd = false;
-                for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
-                    const double shift = attempt == 0 ? 0.0 : 1e-14 * trc;
+                {
+#ifdef TMPC_LP_DEBUG
+                    static const double piv_tol = getenv("LP_PIV") ? atof(getenv("LP_PIV")) : 1e-12;
+#else
+                    constexpr double piv_tol = 1e-12;
+#endif
                     const int i = lane < D ? lane : 0;
 #pragma unroll
                     for (int j = 0; j < D; ++j) {
                         const int lo = i < j ? i : j, hi = i < j ? j : i;
                         double v = sums[lp_col_off<D>(lo) + hi - lo];
-                        if (i == j) v = (i < d) ? v + shift : 1.0;
+                        if (i == j && i >= d) v = 1.0;
                         mrow[j] = (lane < D) ? v : 0.0;
                     }
-                    bb = rhs_i;
-                    mdinv = 1.0;
-                    spd = rows_factor<D>(mrow, bb, mdinv, lane);
+                    spd = lp_factor<D>(mrow, bb, mdinv, piv_tol, lane);
                 }
                 if (!spd) { st = TMPC_STATUS_NUMERICAL; break; }
                 {
@@ -319,7 +399,156 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
             // ------------------------------------------------------------ hand-over: primal active-set steps
             bool ok = false;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // (s, lam) are read across lanes from here on
-            {
+            if (stalled) {
+                // ---- the collapsed iterate lies ON its active rows (their slack is round-off): feasible ascent directions.
+                // Non-negative least squares (Lawson, Hanson) over the active rows A(x): y >= 0 minimising |c - H_A' y|, the
+                // residual p then has a_j . p <= 0 on all of A(x) -- an ascent direction that no active row blocks, however
+                // many of them meet at x.  p = 0: x is optimal, y its certificate.  Otherwise x moves along p to the first
+                // row in the way (a step of positive length: the value rises, no face comes back), which joins A(x).
+                // The multipliers stay non-negative by construction (the step from y to the least-squares solution of a new
+                // passive set stops where the first one reaches zero, that row leaves), |p| never rises while x stays.
+                // p = c - H_W' y carries round-off of size eps |c| along the passive rows, as large as p itself near the
+                // end: it is projected onto their null space once more before use, so that p stays a direction of the face
+                // (and c . p = |p|^2 > 0) down to |p| ~ 1e-13.
+                constexpr double ACT = 1e-11;       // slack <= ACT max(|h_r|, 1): active (the primal feasibility tolerance)
+                int m = 0;
+                if (lane < D) { xpv[lane] = xv[lane]; yv[lane] = 0.0; }
+                lds_fence();
+                const int max_rounds = 8 * d + 32;
+                for (int round = 0; round < max_rounds; ++round) {
+                    double gw[D], srow[D], sdinv = 1.0;
+                    if (!lp_face_factor<D>(Ht, nrp, widx, m, GW, gw, srow, sdinv, lane)) break;
+                    const bool inw = lane < m;
+                    double pl_ = 0.0;
+                    for (int pass = 0; pass < 3; ++pass) {
+                        // pass 0: p = c - GW' y; then p -= GW' S^-1 GW p, twice
+                        if (pass > 0) {
+                            double b2 = 0.0;
+                            if (inw) {
+#pragma unroll
+                                for (int k = 0; k < D; ++k) b2 = fma(gw[k], pv[k], b2);
+                            }
+                            rows_forward<D>(srow, b2, lane);
+                            const double dl = rows_backsub_lane<D>(srow, b2, sdinv, lane);
+                            if (lane < D) tv[lane] = inw ? dl : 0.0;
+                            lds_fence();
+                        }
+                        if (lane < D) {
+                            double v = pass == 0 ? cv[lane] : pv[lane];
+                            const double *coef = pass == 0 ? yv : tv;
+                            for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], coef[a], v);
+                            pv[lane] = v;
+                            pl_ = fabs(v);
+                        }
+                        lds_fence();
+                        if (m == 0) break;
+                    }
+                    const double pn = wave_reduce<OpMax>(pl_);
+                    if (pn <= DUAL_TOL_P) { ok = true; break; }
+                    // ---- one sweep over the rows: the active row that wants in most, the first row in the way
+                    double wbest = 0.0, tbest = INFINITY;
+                    int wrow = -1, trow = -1;
+                    bool infeas = false;
+                    for (int r = lane; r < nr; r += WAVE) {
+                        double gx = 0.0, gp = 0.0;
+#pragma unroll
+                        for (int j = 0; j < D; ++j) {
+                            const double g = Ht[static_cast<size_t>(j) * nrp + r];
+                            gx = fma(g, xpv[j], gx);
+                            gp = fma(g, pv[j], gp);
+                        }
+                        bool isw = false;
+                        for (int a = 0; a < m; ++a) isw = isw || (widx[a] == r);
+                        const double hr = hrow(r);
+                        const double sl = hr - gx;
+                        const double hi = fmax(fabs(hr), 1.0);
+                        const bool active = sl <= ACT * hi;
+                        infeas = infeas || sl < -ACT * hi;
+                        if (!isw && active && gp > wbest) { wbest = gp; wrow = r; }
+                        if (!isw && !active && gp > 1e-14) {
+                            const double t = sl / gp;
+                            if (t < tbest) { tbest = t; trow = r; }
+                        }
+                    }
+                    const double wmax = wave_reduce<OpMax>(wbest);
+#ifdef TMPC_LP_DEBUG
+                    {
+                        double ol = lane < D ? cv[lane] * xpv[lane] : 0.0;
+                        ol = wave_reduce<OpSum>(ol);
+                        const double tm = wave_reduce<OpMin>(tbest);
+                        double ymn = lane < m ? yv[lane] : INFINITY;
+                        ymn = wave_reduce<OpMin>(ymn);
+                        if (lane == 0) printf("lp %lld   nnls %d m %d pn %.3e wmax %.3e obj %.12e tmin %.3e ymin %.3e\n", (long long)b, round, m, pn, wmax, ol, tm, ymn);
+                    }
+#endif
+                    // a long step along a short p took x across a row (what p keeps of the round-off of c - GW' y, times the
+                    // length of the step): no certificate from here
+                    if (__ballot(infeas) != 0ull) break;
+                    if (wmax > 1e-14) {
+                        // a_j . p > 0 on an active row: j joins the passive set
+                        if (m >= d) break;
+                        const unsigned long long bal = __ballot(wbest == wmax);
+                        const int j = __builtin_amdgcn_readlane(wrow, __ffsll(static_cast<long long>(bal)) - 1);
+                        if (lane == 0) { widx[m] = j; yv[m] = 0.0; }
+                        ++m;
+                        lds_fence();
+                        bool bad = false;
+                        for (int inner = 0; inner <= d; ++inner) {
+                            const bool in2 = lane < m;
+                            if (!lp_face_factor<D>(Ht, nrp, widx, m, GW, gw, srow, sdinv, lane)) { bad = true; break; }
+                            // z = argmin |c - GW' z| (refined twice), in tv
+                            if (lane < D) tv[lane] = 0.0;
+                            lds_fence();
+                            for (int sweep = 0; sweep < 3; ++sweep) {
+                                if (lane < D) {
+                                    double v = cv[lane];
+                                    for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], tv[a], v);
+                                    pv[lane] = v;                   // (p is formed again at the top of the next round)
+                                }
+                                lds_fence();
+                                double b2 = 0.0;
+                                if (in2) {
+#pragma unroll
+                                    for (int k = 0; k < D; ++k) b2 = fma(gw[k], pv[k], b2);
+                                }
+                                rows_forward<D>(srow, b2, lane);
+                                const double zs = rows_backsub_lane<D>(srow, b2, sdinv, lane);
+                                if (in2) tv[lane] += zs;
+                                lds_fence();
+                            }
+                            const double zl = in2 ? tv[lane] : INFINITY, yl = in2 ? yv[lane] : 0.0;
+                            const double zmin = wave_reduce<OpMin>(zl);
+                            if (zmin > 0.0) {
+                                if (in2) yv[lane] = zl;
+                                lds_fence();
+                                break;
+                            }
+                            // towards z until the first multiplier reaches zero; that row leaves
+                            const double al = (in2 && zl <= 0.0) ? yl / (yl - zl) : INFINITY;
+                            const double alpha = wave_reduce<OpMin>(al);
+                            const unsigned long long bl = __ballot(in2 && al == alpha);
+                            const int i = __ffsll(static_cast<long long>(bl)) - 1;
+                            if (i == m - 1 && inner == 0) { bad = true; break; }      // the row that has just come in: round-off
+                            const double yn = in2 ? fmax(yl + alpha * (zl - yl), 0.0) : 0.0;
+                            const int wmove = in2 ? widx[lane] : 0;
+                            lds_fence();
+                            if (in2 && lane < i) yv[lane] = yn;
+                            if (in2 && lane > i) { yv[lane - 1] = yn; widx[lane - 1] = wmove; }
+                            --m;
+                            lds_fence();
+                        }
+                        // an active row in the way that the passive set cannot take (dependent on it to working precision):
+                        // no direction to go on with
+                        if (bad) break;
+                        continue;
+                    }
+                    // ---- no active row in the way: along p to the first inactive one
+                    const double tmin = wave_reduce<OpMin>(tbest);
+                    if (!(tmin < INFINITY)) { st = TMPC_STATUS_UNBOUNDED; break; }
+                    if (lane < D) xpv[lane] += tmin * pv[lane];
+                    lds_fence();
+                }
+            } else {
                 // candidates: rows with lam > s, at most one per lane
                 int ncand = 0;
                 for (int r0 = 0; r0 < nrp; r0 += WAVE) {
@@ -384,7 +613,12 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                             srow[c2] = (inw && c2 < m) ? v : ((c2 == lane) ? 1.0 : 0.0);
                         }
                         double bdummy = 0.0;
-                        if (!rows_factor<D>(srow, bdummy, sdinv, lane)) break;
+                        if (!rows_factor<D>(srow, bdummy, sdinv, lane)) {
+#ifdef TMPC_LP_DEBUG
+                            if (lane == 0) printf("lp %lld   round %d m %d: working rows dependent\n", (long long)b, round, m);
+#endif
+                            break;
+                        }
                         if (lane < D) yv[lane] = 0.0;
                         lds_fence();
                         for (int sweep = 0; sweep < 2; ++sweep) {
@@ -456,6 +690,9 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                             }
                         }
                         const double vmax = wave_reduce<OpMax>(vbest);
+#ifdef TMPC_LP_DEBUG
+                        if (lane == 0) printf("lp %lld   round %d m %d ncand %d pn %.3e ymin %.3e ymax %.3e vmax %.3e\n", (long long)b, round, m, ncand, pn, ymin, ymax, vmax);
+#endif
                         if (vmax > 0.0) {
                             // a violated row enters; it replaces the working row it is nearly parallel to
                             const unsigned long long bal = __ballot(vbest == vmax);
@@ -480,7 +717,7 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                             lds_fence();
                             continue;
                         }
-                        if (m > 0 && ymin < -1e-10 * ymax) {
+                        if (m > 0 && ymin < -DUAL_TOL_Y * ymax) {
                             // the most negative multiplier leaves
                             const unsigned long long bal = __ballot(inw && ymin_l == ymin);
                             const int i = __ffsll(static_cast<long long>(bal)) - 1;
@@ -491,7 +728,7 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                             lds_fence();
                             continue;
                         }
-                        if (pn > 1e-11) {
+                        if (pn > DUAL_TOL_P) {
                             // c has a component along the face: follow it to the blocking row
                             const double tmin = wave_reduce<OpMin>(tbest);
                             if (!(tmin < INFINITY)) { st = TMPC_STATUS_UNBOUNDED; break; }
@@ -509,10 +746,18 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                     }
                 }
             }
+#ifdef TMPC_LP_DEBUG
+            if (lane == 0) printf("lp %lld hand-over at it %d tol %.1e: ok %d st %d\n", (long long)b, it, try_tol, (int)ok, st);
+#endif
             if (st == TMPC_STATUS_UNBOUNDED) break;
             if (ok) { st = TMPC_STATUS_OPTIMAL; from_polish = true; break; }
-            if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
-            try_tol *= 1e-2;
+            if (stalled) break;                                          // MAX_ITER: the iterate, without a certificate
+            if (try_tol <= 1e-12) {
+                if (rdn_last <= DUAL_TOL_P) { st = TMPC_STATUS_OPTIMAL; break; }
+                collapse = true;                                         // on until the gap has collapsed, then the steps above
+            } else {
+                try_tol *= 1e-2;
+            }
         }
 
         // ---- outputs (scaled back: x by hm, the value by |c| hm)
@@ -537,11 +782,20 @@ template <int D, bool STAGED>
 hipError_t launch_lp_ds(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
                         double *xout, int32_t *status, int32_t *iters, hipStream_t stream) {
     const size_t lds = (static_cast<size_t>(LpLds<D>::TOTAL) * LP_WPB + (STAGED ? static_cast<size_t>(D) * p.nrp : 0)) * sizeof(double);
+#ifdef TMPC_HOST_SIM
+    // tests/wavesim: one workgroup (four waves, four LPs in flight) on the host execution model takes the whole batch
+    (void)nblocks; (void)stream;
+    sim::Dim3 bi, gd;
+    bi.x = bi.y = bi.z = 0;
+    sim::run_block(WAVE * LP_WPB, lds, bi, gd, [&]() { lp_kernel<D, STAGED>(p, B, C, relax, ws, val, xout, status, iters); });
+    return hipSuccess;
+#else
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lp_kernel<D, STAGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds));
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((lp_kernel<D, STAGED>), dim3(nblocks), dim3(WAVE * LP_WPB), lds, stream, p, B, C, relax, ws, val, xout, status, iters);
     return hipGetLastError();
+#endif
 }
 
 template <int D>
@@ -563,12 +817,20 @@ int lp_workspace_arrays() { return LP_ARR; }
 
 hipError_t launch_lp(const LpDevice &p, int64_t B, int nblocks, const double *C, const int32_t *relax, double *ws, double *val,
                      double *xout, int32_t *status, int32_t *iters, hipStream_t stream) {
+    // (tests/wavesim: the sanitizer builds stop at TMPC_LP_MAX_DIM = 8 or 12; d = 32 alone takes them half an hour)
+#ifndef TMPC_LP_MAX_DIM
+#define TMPC_LP_MAX_DIM 32
+#endif
     switch (lp_padded_dim(p.d)) {
     case 4: return launch_lp_d<4>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
     case 8: return launch_lp_d<8>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+#if TMPC_LP_MAX_DIM >= 12
     case 12: return launch_lp_d<12>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+#endif
+#if TMPC_LP_MAX_DIM >= 32
     case 16: return launch_lp_d<16>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
     case 32: return launch_lp_d<32>(p, B, nblocks, C, relax, ws, val, xout, status, iters, stream);
+#endif
     default: return hipErrorInvalidValue;
     }
 }

@@ -282,3 +282,21 @@ def test_darup_known_answer_with_the_lp_kernel(hip_lib, hip_lp):
     finally:
         pl.set_lp_backend(old)
     assert got.A.shape == want.A.shape and np.allclose(got.A, want.A, atol=1e-9) and np.allclose(got.b, want.b, atol=1e-8)
+
+
+@pytest.mark.gpu
+def test_degenerate_faces_finish_with_certificate(hip_lib):
+    """tests/golden/lp_degenerate_cases.npz (the six LPs per cartpole model that the round-2 kernel returned at its
+    iteration cap, see tests/test_wavesim.py): status 0 through the C ABI, values against HiGHS run with 1e-10 tolerances."""
+    from scipy.optimize import linprog
+    Z = np.load(os.path.join(common.GOLDEN, "lp_degenerate_cases.npz"))
+    for name in ("a", "b"):
+        H, h, Cm, rel = (Z[f"{name}_{k}"] for k in ("H", "h", "C", "rel"))
+        raw = hip_lib.lp_batch(H, h, Cm, relax=rel, relax_by=1.0, want_x=True)
+        assert np.all(raw["status"] == 0) and raw["iters"].max() <= 40
+        for c, r, v, x in zip(Cm, rel, raw["val"], raw["x"]):
+            hk = h + (np.arange(len(h)) == r) * 1.0
+            res = linprog(-c, A_ub=H, b_ub=hk, bounds=(None, None), method="highs",
+                          options=dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10))
+            assert res.status == 0 and abs(v + res.fun) <= 1e-9 * max(1.0, abs(res.fun))
+            assert np.max((H @ x - hk) / np.maximum(np.abs(hk), 1.0)) <= 1e-10

@@ -144,3 +144,75 @@ def test_block_kernel_source_under_sanitizers(block_binaries, cartpole, oracle_l
         nontrivial += int((o["iters"] > 0).sum())
         assert o["rendezvous"] > 1000
     assert nontrivial >= 20
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the batched LP kernel of the offline stage (csrc/tmpc_lp.hip) on the same execution model
+def _highs(H, h, C, rel, relax_by=1.0):
+    from scipy.optimize import linprog
+    val = np.empty(len(C))
+    for k, c in enumerate(C):
+        hk = h.copy()
+        if rel is not None and rel[k] >= 0:
+            hk[rel[k]] += relax_by
+        # (HiGHS' default feasibility tolerance of 1e-7 leaves 3e-8 of violation, and of value, on these sets)
+        res = linprog(-c, A_ub=H, b_ub=hk, bounds=(None, None), method="highs",
+                      options=dict(primal_feasibility_tolerance=1e-10, dual_feasibility_tolerance=1e-10))
+        assert res.status == 0
+        val[k] = -res.fun
+    return val
+
+
+def test_lp_kernel_source_under_asan_degenerate_faces(binaries):
+    """tests/golden/lp_degenerate_cases.npz: support functions of the cartpole's terminal sets (452 and 588 rows, d = 9) in
+    directions whose optimal face has dimension >= 1 -- the normal matrix loses its rank as the gap closes.  The round-2
+    kernel divided by pivots that were round-off, drifted along the face, never got its dual residual back and returned
+    the iterate at the iteration cap (status 1, value off by 6e-9); with the skipped pivots (lp_factor) the vertex steps
+    finish.  Values against HiGHS run with 1e-10 feasibility tolerances: 1e-9 relative."""
+    Z = np.load(os.path.join(common.GOLDEN, "lp_degenerate_cases.npz"))
+    for name in ("a", "b"):
+        H, h, C, rel = (Z[f"{name}_{k}"] for k in ("H", "h", "C", "rel"))
+        out = run_case.run_lp(binaries["lpsim_asan"], H, h, C, relax=rel, env=SAN_ENV)
+        assert_clean(out)
+        assert np.all(out["status"] == 0), out["status"]
+        assert out["iters"].max() <= 40
+        ref = _highs(H, h, C, rel)
+        assert np.max(np.abs(out["val"] - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-9
+        for x, c, r, v in zip(out["x"], C, rel, out["val"]):
+            hk = h + (np.arange(len(h)) == r) * 1.0
+            assert np.max((H @ x - hk) / np.maximum(np.abs(hk), 1.0)) <= 1e-10 and abs(c @ x - v) <= 1e-9 * max(1.0, abs(v))
+
+
+def test_lp_kernel_source_under_msan(binaries):
+    """Random polytopes (d = 3, 6), a box with duplicated and nearly parallel rows and objectives along its rows (whole
+    facets optimal), an unbounded direction and an empty set: the verdicts, the values against HiGHS, and no read of an
+    uninitialised word (the per-wave work space starts out poisoned)."""
+    rng = np.random.default_rng(4)
+    for d, nr in ((3, 70), (6, 130)):
+        H = rng.standard_normal((nr, d))
+        h = 1.0 + rng.random(nr)
+        C = rng.standard_normal((6, d))
+        out = run_case.run_lp(binaries["lpsim_msan"], H, h, C, env=SAN_ENV)
+        assert_clean(out)
+        assert np.all(out["status"] == 0)
+        ref = _highs(H, h, C, None)
+        assert np.max(np.abs(out["val"] - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-9
+    d = 5
+    box = np.r_[np.eye(d), -np.eye(d)]
+    tilt = box[:4] + 1e-7 * rng.standard_normal((4, d))
+    H = np.r_[box, box[:3], tilt]
+    h = np.r_[np.ones(2 * d), np.ones(3), np.ones(4) + 1e-9]
+    C = np.r_[box[:4], tilt[:2], np.ones((1, d))]
+    rel = np.array([-1, -1, 0, 1, -1, 10, -1], dtype=np.int32)
+    out = run_case.run_lp(binaries["lpsim_msan"], H, h, C, relax=rel, env=SAN_ENV)
+    assert_clean(out)
+    assert np.all(out["status"] == 0), out["status"]
+    ref = _highs(H, h, C, rel)
+    assert np.max(np.abs(out["val"] - ref) / np.maximum(np.abs(ref), 1.0)) <= 1e-8
+    # a half space is unbounded along its normal's orthogonal complement; x <= -1, -x <= -1 is empty
+    out = run_case.run_lp(binaries["lpsim_msan"], np.array([[1.0, 0.0], [0.0, 1.0]]), np.ones(2), np.array([[-1.0, 0.0], [1.0, 1.0]]), env=SAN_ENV)
+    assert_clean(out)
+    assert out["status"][0] == 4 and np.isinf(out["val"][0]) and out["status"][1] == 0 and abs(out["val"][1] - 2.0) <= 1e-12
+    out = run_case.run_lp(binaries["lpsim_msan"], np.array([[1.0], [-1.0]]), np.array([-1.0, -1.0]), np.array([[1.0]]), env=SAN_ENV)
+    assert_clean(out)
+    assert out["status"][0] == 2

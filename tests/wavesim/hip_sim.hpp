@@ -324,6 +324,8 @@ inline long long sim_clock() { static long long t = 0; return t += 7; }
 inline unsigned long long __ballot(bool p) { return sim::ballot(p); }
 inline int __any(bool p) { return sim::ballot(p) != 0ull; }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+#define __builtin_amdgcn_fence(order, scope) sim::wave_fence()
 inline int __double2loint(double v) { int64_t u; std::memcpy(&u, &v, 8); return static_cast<int>(u & 0xffffffffll); }
 inline int __double2hiint(double v) { int64_t u; std::memcpy(&u, &v, 8); return static_cast<int>(u >> 32); }
 inline double __hiloint2double(int hi, int lo) {

@@ -15,7 +15,8 @@ BUILD = os.path.join(HERE, "_build")
 def build_all(extra="-DTMPC_SIM_SHAPES"):
     """every binary of the Makefile in one parallel make (what __graft_entry__.build() runs as well); up to date -> no-op"""
     subprocess.check_call(["make", "-s", "-j6", "-C", HERE, "all", f"EXTRA={extra}"])
-    return {t: os.path.join(BUILD, t) for t in ("wavesim", "wavesim_asan", "wavesim_msan", "blocksim", "blocksim_asan", "blocksim_msan")}
+    return {t: os.path.join(BUILD, t) for t in ("wavesim", "wavesim_asan", "wavesim_msan", "blocksim", "blocksim_asan", "blocksim_msan",
+                                                 "lpsim_asan", "lpsim_msan")}
 
 
 def run(binary, d, X, R, variant=None, env=None, timeout=1800, block=False):
@@ -66,3 +67,35 @@ def run(binary, d, X, R, variant=None, env=None, timeout=1800, block=False):
             return o
     finally:
         _native.destroy(h)
+
+
+def run_lp(binary, H, h, Cmat, relax=None, relax_by=1.0, env=None, timeout=1800):
+    """the batched LP kernel (lpsim binaries) on the layout tmpc_debug_dump_lp_layout writes for the polytope (H, h)"""
+    from LinearMPCOverNetworks import _native
+    L = _native.lib()
+    L.tmpc_debug_dump_lp_layout.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_char_p]
+    L.tmpc_debug_dump_lp_layout.restype = C.c_int
+    H = np.ascontiguousarray(H, dtype=np.float64)
+    h = np.ascontiguousarray(h, dtype=np.float64).reshape(-1)
+    Cm = np.ascontiguousarray(np.atleast_2d(Cmat), dtype=np.float64)
+    nr, d = H.shape
+    B = Cm.shape[0]
+    with tempfile.TemporaryDirectory() as tmp:
+        lay, batch, out = (os.path.join(tmp, n) for n in ("layout.bin", "batch.bin", "out.bin"))
+        rc = L.tmpc_debug_dump_lp_layout(d, nr, H.ctypes.data_as(C.c_void_p), h.ctypes.data_as(C.c_void_p), float(relax_by), lay.encode())
+        if rc != 0:
+            raise RuntimeError(f"tmpc_debug_dump_lp_layout failed ({rc}): {L.tmpc_last_error(None).decode()}")
+        with open(batch, "wb") as f:
+            np.array([B, 0 if relax is None else 1], dtype=np.int64).tofile(f)
+            Cm.tofile(f)
+            if relax is not None:
+                np.ascontiguousarray(relax, dtype=np.int32).reshape(B).tofile(f)
+        res = subprocess.run([binary, lay, batch, out], capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
+        if res.returncode != 0:
+            raise RuntimeError(f"{os.path.basename(binary)} failed ({res.returncode}):\n{res.stderr[-8000:]}")
+        raw = open(out, "rb").read()
+    val = np.frombuffer(raw, np.float64, B, 0)
+    x = np.frombuffer(raw, np.float64, B * d, 8 * B).reshape(B, d)
+    st = np.frombuffer(raw, np.int32, B, 8 * B * (d + 1))
+    it = np.frombuffer(raw, np.int32, B, 8 * B * (d + 1) + 4 * B)
+    return dict(val=val, x=x, status=st, iters=it, stderr=res.stderr, stdout=res.stdout)
