@@ -163,7 +163,7 @@ def lp_max_batch(C, A, b, relax=None, relax_by: float = 1.0, want_x: bool = Fals
         out = _native.lp_batch(A, b, C, relax=rel, relax_by=relax_by, device=_LP_DEVICE, want_x=want_x)
         st = np.select([out["status"] == 0, out["status"] == 1, out["status"] == 2, out["status"] == 4], [0, 1, 2, 3], default=4).astype(int)
         # kernel status 1: the interior-point iterate was returned without its certificate (feasible to 1e-11, multipliers
-        # >= 0, dual residual <= 1e-11).  Round 3: none of the 7 458 LPs of a cartpole model, 3 % of the 2 092 of the
+        # >= 0, dual residual <= 1e-11).  Round 3: none of the 7 458 LPs of a cartpole model, 1 % of the 2 092 of the
         # synthetic one (d = 28: c keeps ~1e-8 along a long optimal face, below what double precision resolves there);
         # the value is within ~1e-8.  These values feed the constraint tightening, so such an LP is solved again by HiGHS
         # -- the call the reference makes for every LP (utils_polytope.py:19) -- instead of being passed on as "solved".

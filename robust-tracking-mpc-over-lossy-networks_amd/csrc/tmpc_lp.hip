@@ -14,8 +14,10 @@
 //   1. Mehrotra predictor-corrector on the normal equations M = H' diag(lam / s) H (d x d, rows of M on the lanes,
 //      LDL' by readlane elimination), infeasible start -- same iteration as the QP kernels without the Hessian.  Pivots
 //      that have become round-off are skipped (lp_factor): on an optimal face of dimension >= 1 M loses its rank.
-//   2. Hand-over at tol: the rows with lam > s are the IPM's guess of the optimal face.  A greedy pass keeps the most
-//      active ones that are linearly independent; primal active-set steps then make the answer exact: project onto the face,
+//   2. Hand-over at tol: the rows with lam > s are the IPM's guess of the optimal face.  Non-negative least squares over
+//      them (y >= 0 minimising |c - H' y|) picks the working rows -- the ones with y > 0 -- and gives a certificate that
+//      needs no vertex: the iterate is strictly feasible, y is dual feasible, so the value lies within sum y_i s_i +
+//      |c - H' y| |x| of c . x (accepted below 1e-11).  Primal active-set steps then make the answer exact: project onto the face,
 //      multipliers by least squares; a violated row replaces the working row it is (nearly) parallel to, a negative
 //      multiplier leaves, a remaining component of c along the face is followed to the blocking row.  Accept when the
 //      point is feasible, the multipliers are non-negative and c is in the cone of the working rows.
@@ -48,10 +50,13 @@ using namespace wv;
 
 constexpr int LP_WPB = 4;        // waves (= LPs in flight) per workgroup
 constexpr int LP_ARR = 6;        // per-row workspace arrays: s, lam, Hx, w, ds, dlam
-// dual feasibility of an accepted answer, for |c| = 1: multipliers >= -DUAL_TOL_Y max(y), |c - H_W' y|_inf <= DUAL_TOL_P.
-// What c keeps along the face is paid for with the length of the face: on the terminal sets of the synthetic model
-// (d = 28) a residual of 8e-10 left 2e-8 of the value behind.  Primal feasibility: 1e-11 max(|h_r|, 1).
-constexpr double DUAL_TOL_Y = 1e-10, DUAL_TOL_P = 1e-11;
+// dual feasibility of an accepted answer, for |c| = 1: multipliers >= -DUAL_TOL_Y max(y), |c - H_W' y|_inf <= DUAL_TOL_P
+// (HiGHS behind the reference's linprog calls: 1e-7).  What c keeps along the face is paid for with the length of the
+// face: on the terminal sets of the synthetic model (d = 28) a residual of 8e-10 left 2e-8 of the value behind, so
+// 1e-10 keeps the value to a few 1e-9.  Primal feasibility: 1e-11 max(|h_r|, 1).
+constexpr double DUAL_TOL_Y = 1e-10, DUAL_TOL_P = 1e-10;
+// duality gap, relative to max(|val|, 1) in kernel units, of an answer that is accepted without being a point of the face
+constexpr double GAP_TOL = 1e-11;
 
 template <int D> __host__ __device__ constexpr int lp_col_off(int j) { return j * D - j * (j - 1) / 2; }
 
@@ -179,6 +184,98 @@ __device__ __forceinline__ bool lp_face_factor(const double *__restrict__ Ht, in
     double bdummy = 0.0;
     sdinv = 1.0;
     return rows_factor<D>(srow, bdummy, sdinv, lane);
+}
+
+// One outer step of non-negative least squares (Lawson, Hanson) for  min |c - H_W' y|, y >= 0:  row j joins the passive
+// set W (widx[0 .. m), multipliers yv), the least-squares multipliers z of the new set are computed (tv; refined twice), and
+// y moves towards z -- all the way if z > 0, otherwise to where the first multiplier reaches zero; that row leaves and the
+// step is repeated on the smaller set.  y >= 0 throughout, |c - H_W' y| does not rise.  False (W, y as before): j depends on
+// W to working precision, or comes out again at once (a_j . p > 0 was round-off).  pv is scratch.
+template <int D>
+__device__ __forceinline__ bool lp_nnls_add(const double *__restrict__ Ht, int nrp, int d, int j, const double *cv, int *widx, int &m,
+                                            double *GW, double *yv, double *tv, double *pv, int lane) {
+    if (lane == 0) { widx[m] = j; yv[m] = 0.0; }
+    ++m;
+    lds_fence();
+    for (int inner = 0; inner <= d; ++inner) {
+        const bool inw = lane < m;
+        double gw[D], srow[D], sdinv = 1.0;
+        if (!lp_face_factor<D>(Ht, nrp, widx, m, GW, gw, srow, sdinv, lane)) {
+            if (inner == 0) { --m; lds_fence(); return false; }
+            break;                                                  // (a subset of a set that factored: not expected)
+        }
+        if (lane < D) tv[lane] = 0.0;
+        lds_fence();
+        for (int sweep = 0; sweep < 3; ++sweep) {
+            if (lane < D) {
+                double v = cv[lane];
+                for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], tv[a], v);
+                pv[lane] = v;
+            }
+            lds_fence();
+            double b2 = 0.0;
+            if (inw) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) b2 = fma(gw[k], pv[k], b2);
+            }
+            rows_forward<D>(srow, b2, lane);
+            const double zs = rows_backsub_lane<D>(srow, b2, sdinv, lane);
+            if (inw) tv[lane] += zs;
+            lds_fence();
+        }
+        const double zl = inw ? tv[lane] : INFINITY, yl = inw ? yv[lane] : 0.0;
+        const double zmin = wave_reduce<OpMin>(zl);
+        if (zmin > 0.0) {
+            if (inw) yv[lane] = zl;
+            lds_fence();
+            break;
+        }
+        const double al = (inw && zl <= 0.0) ? yl / (yl - zl) : INFINITY;
+        const double alpha = wave_reduce<OpMin>(al);
+        const unsigned long long bl = __ballot(inw && al == alpha);
+        const int i = __ffsll(static_cast<long long>(bl)) - 1;
+        if (i == m - 1 && inner == 0) { --m; lds_fence(); return false; }
+        const double yn = inw ? fmax(yl + alpha * (zl - yl), 0.0) : 0.0;
+        const int wmove = inw ? widx[lane] : 0;
+        lds_fence();
+        if (inw && lane < i) yv[lane] = yn;
+        if (inw && lane > i) { yv[lane - 1] = yn; widx[lane - 1] = wmove; }
+        --m;
+        lds_fence();
+    }
+    return true;
+}
+
+// p = c - H_W' y, projected onto the null space of the passive rows twice more (gw, srow, sdinv: lp_face_factor of W):
+// the subtraction leaves round-off of size eps |c| along the rows of W, as large as p itself near the end.  |p|_inf.
+template <int D>
+__device__ __forceinline__ double lp_face_residual(int m, const double *cv, const double *GW, const double *yv, double *tv, double *pv,
+                                                   const double (&gw)[D], const double (&srow)[D], double sdinv, int lane) {
+    const bool inw = lane < m;
+    double pl_ = 0.0;
+    for (int pass = 0; pass < 3; ++pass) {
+        if (pass > 0) {
+            double b2 = 0.0;
+            if (inw) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) b2 = fma(gw[k], pv[k], b2);
+            }
+            rows_forward<D>(srow, b2, lane);
+            const double dl = rows_backsub_lane<D>(srow, b2, sdinv, lane);
+            if (lane < D) tv[lane] = inw ? dl : 0.0;
+            lds_fence();
+        }
+        if (lane < D) {
+            double v = pass == 0 ? cv[lane] : pv[lane];
+            const double *coef = pass == 0 ? yv : tv;
+            for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], coef[a], v);
+            pv[lane] = v;
+            pl_ = fabs(v);
+        }
+        lds_fence();
+        if (m == 0) break;
+    }
+    return wave_reduce<OpMax>(pl_);
 }
 
 // STAGED: H' (D x nrp doubles) is copied to LDS once per workgroup and every row sweep reads it from there; otherwise
@@ -418,32 +515,7 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                 for (int round = 0; round < max_rounds; ++round) {
                     double gw[D], srow[D], sdinv = 1.0;
                     if (!lp_face_factor<D>(Ht, nrp, widx, m, GW, gw, srow, sdinv, lane)) break;
-                    const bool inw = lane < m;
-                    double pl_ = 0.0;
-                    for (int pass = 0; pass < 3; ++pass) {
-                        // pass 0: p = c - GW' y; then p -= GW' S^-1 GW p, twice
-                        if (pass > 0) {
-                            double b2 = 0.0;
-                            if (inw) {
-#pragma unroll
-                                for (int k = 0; k < D; ++k) b2 = fma(gw[k], pv[k], b2);
-                            }
-                            rows_forward<D>(srow, b2, lane);
-                            const double dl = rows_backsub_lane<D>(srow, b2, sdinv, lane);
-                            if (lane < D) tv[lane] = inw ? dl : 0.0;
-                            lds_fence();
-                        }
-                        if (lane < D) {
-                            double v = pass == 0 ? cv[lane] : pv[lane];
-                            const double *coef = pass == 0 ? yv : tv;
-                            for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], coef[a], v);
-                            pv[lane] = v;
-                            pl_ = fabs(v);
-                        }
-                        lds_fence();
-                        if (m == 0) break;
-                    }
-                    const double pn = wave_reduce<OpMax>(pl_);
+                    const double pn = lp_face_residual<D>(m, cv, GW, yv, tv, pv, gw, srow, sdinv, lane);
                     if (pn <= DUAL_TOL_P) { ok = true; break; }
                     // ---- one sweep over the rows: the active row that wants in most, the first row in the way
                     double wbest = 0.0, tbest = INFINITY;
@@ -489,54 +561,7 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                         if (m >= d) break;
                         const unsigned long long bal = __ballot(wbest == wmax);
                         const int j = __builtin_amdgcn_readlane(wrow, __ffsll(static_cast<long long>(bal)) - 1);
-                        if (lane == 0) { widx[m] = j; yv[m] = 0.0; }
-                        ++m;
-                        lds_fence();
-                        bool bad = false;
-                        for (int inner = 0; inner <= d; ++inner) {
-                            const bool in2 = lane < m;
-                            if (!lp_face_factor<D>(Ht, nrp, widx, m, GW, gw, srow, sdinv, lane)) { bad = true; break; }
-                            // z = argmin |c - GW' z| (refined twice), in tv
-                            if (lane < D) tv[lane] = 0.0;
-                            lds_fence();
-                            for (int sweep = 0; sweep < 3; ++sweep) {
-                                if (lane < D) {
-                                    double v = cv[lane];
-                                    for (int a = 0; a < m; ++a) v = fma(-GW[a * D + lane], tv[a], v);
-                                    pv[lane] = v;                   // (p is formed again at the top of the next round)
-                                }
-                                lds_fence();
-                                double b2 = 0.0;
-                                if (in2) {
-#pragma unroll
-                                    for (int k = 0; k < D; ++k) b2 = fma(gw[k], pv[k], b2);
-                                }
-                                rows_forward<D>(srow, b2, lane);
-                                const double zs = rows_backsub_lane<D>(srow, b2, sdinv, lane);
-                                if (in2) tv[lane] += zs;
-                                lds_fence();
-                            }
-                            const double zl = in2 ? tv[lane] : INFINITY, yl = in2 ? yv[lane] : 0.0;
-                            const double zmin = wave_reduce<OpMin>(zl);
-                            if (zmin > 0.0) {
-                                if (in2) yv[lane] = zl;
-                                lds_fence();
-                                break;
-                            }
-                            // towards z until the first multiplier reaches zero; that row leaves
-                            const double al = (in2 && zl <= 0.0) ? yl / (yl - zl) : INFINITY;
-                            const double alpha = wave_reduce<OpMin>(al);
-                            const unsigned long long bl = __ballot(in2 && al == alpha);
-                            const int i = __ffsll(static_cast<long long>(bl)) - 1;
-                            if (i == m - 1 && inner == 0) { bad = true; break; }      // the row that has just come in: round-off
-                            const double yn = in2 ? fmax(yl + alpha * (zl - yl), 0.0) : 0.0;
-                            const int wmove = in2 ? widx[lane] : 0;
-                            lds_fence();
-                            if (in2 && lane < i) yv[lane] = yn;
-                            if (in2 && lane > i) { yv[lane - 1] = yn; widx[lane - 1] = wmove; }
-                            --m;
-                            lds_fence();
-                        }
+                        const bool bad = !lp_nnls_add<D>(Ht, nrp, d, j, cv, widx, m, GW, yv, tv, pv, lane);
                         // an active row in the way that the passive set cannot take (dependent on it to working precision):
                         // no direction to go on with
                         if (bad) break;
@@ -562,37 +587,60 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                 lds_fence();
                 int m = 0;
                 if (ncand <= WAVE) {
-                    // greedy choice: most active first (smallest slack), kept if independent of the rows kept so far
+                    // the working set to start from: non-negative least squares over the candidates, y >= 0 minimising
+                    // |c - H_cand' y| (the rows that end with y > 0).  Among 43 candidates in 28 dimensions "the most active
+                    // ones that are independent" are nearly dependent rows with multipliers of +-30; here a row comes in
+                    // only while it reduces the residual
                     const bool have = lane < ncand;
                     const int myr = have ? cidx[lane] : 0;
                     double R[D];
 #pragma unroll
                     for (int j = 0; j < D; ++j) R[j] = have ? Ht[static_cast<size_t>(j) * nrp + myr] : 0.0;
-                    const double skey = have ? s_[myr] : INFINITY;
                     bool alive = have;
-                    for (int pick = 0; pick < d; ++pick) {
-                        double n2 = 0.0;
+                    if (lane < D) yv[lane] = 0.0;
+                    lds_fence();
+                    double pn_sel = INFINITY;
+                    bool cert = false;
+                    for (int pick = 0;; ++pick) {
+                        double gw[D], srow[D], sdinv = 1.0;
+                        if (!lp_face_factor<D>(Ht, nrp, widx, m, GW, gw, srow, sdinv, lane)) break;
+                        pn_sel = lp_face_residual<D>(m, cv, GW, yv, tv, pv, gw, srow, sdinv, lane);
+                        if (pick >= 2 * d + 8 || m >= d) break;
+                        bool isw = false;
+                        for (int a = 0; a < m; ++a) isw = isw || (widx[a] == myr);
+                        double gp = 0.0;
 #pragma unroll
-                        for (int j = 0; j < D; ++j) n2 = fma(R[j], R[j], n2);
-                        const double key = (alive && n2 > 1e-8) ? skey : INFINITY;
-                        const double kmin = wave_reduce<OpMin>(key);
-                        if (!(kmin < INFINITY)) break;
-                        const unsigned long long bal = __ballot(key == kmin);
+                        for (int j = 0; j < D; ++j) gp = fma(R[j], pv[j], gp);
+                        const double key = (alive && !isw) ? gp : -INFINITY;
+                        const double wmax = wave_reduce<OpMax>(key);
+                        if (!(wmax > 1e-13) || !(wmax > 1e-3 * pn_sel)) break;
+                        const unsigned long long bal = __ballot(key == wmax);
                         const int pl = __ffsll(static_cast<long long>(bal)) - 1;
-                        const double rn = 1.0 / sqrt(readlane_d(n2, pl));
-                        double dot = 0.0;
-                        double q[D];
-#pragma unroll
-                        for (int j = 0; j < D; ++j) { q[j] = readlane_d(R[j], pl) * rn; dot = fma(R[j], q[j], dot); }
-#pragma unroll
-                        for (int j = 0; j < D; ++j) R[j] = fma(-dot, q[j], R[j]);
-                        if (lane == pl) { alive = false; widx[m] = myr; }
-                        ++m;
+                        const int j = __builtin_amdgcn_readlane(myr, pl);
+                        if (!lp_nnls_add<D>(Ht, nrp, d, j, cv, widx, m, GW, yv, tv, pv, lane) && lane == pl) alive = false;
                     }
+                    // ---- certificate without a vertex: x (the iterate: strictly feasible) and y >= 0 on the rows of W with
+                    // c = H_W' y + p bound the value from both sides, c . x <= val <= c . x + sum y_i s_i + |p . (x* - x)|.
+                    // On a degenerate face (rows active with multiplier zero) no projection onto W is feasible, but once the
+                    // gap of the iterate is at 1e-12 this closes by itself.
+                    {
+                        double gl = lane < m ? yv[lane] * fmax(s_[widx[lane]], 0.0) : 0.0;
+                        gl = wave_reduce<OpSum>(gl);
+                        double x1 = lane < D ? fabs(xv[lane]) : 0.0, ol = lane < D ? cv[lane] * xv[lane] : 0.0;
+                        x1 = wave_reduce<OpSum>(x1);
+                        ol = wave_reduce<OpSum>(ol);
+#ifdef TMPC_LP_DEBUG
+                        if (lane == 0) printf("lp %lld   selection m %d pn %.3e gapW %.3e |x|_1 %.3e\n", (long long)b, m, pn_sel, gl, x1);
+#endif
+                        cert = pn_sel <= DUAL_TOL_P && gl + pn_sel * fmax(x1, 1.0) <= GAP_TOL * fmax(fabs(ol), 1.0);
+                    }
+                    {
                     lds_fence();
                     if (lane < D) xpv[lane] = xv[lane];
                     lds_fence();
-                    for (int round = 0; round < 3 * d + 16; ++round) {
+                    // (with the certificate in hand: one projection onto the face of W, for the vertex value if it is feasible)
+                    const int max_rounds = cert ? 1 : d + 12;
+                    for (int round = 0; round < max_rounds; ++round) {
                         // ---- projection onto the face of the working rows, multipliers by least squares
                         const bool inw = lane < m;
                         const int wr = inw ? widx[lane] : 0;
@@ -743,6 +791,12 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                         }
                         ok = true;
                         break;
+                    }
+                    if (!ok && cert && st != TMPC_STATUS_UNBOUNDED) {
+                        if (lane < D) xpv[lane] = xv[lane];
+                        lds_fence();
+                        ok = true;
+                    }
                     }
                 }
             }
