@@ -593,9 +593,6 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                     // only while it reduces the residual
                     const bool have = lane < ncand;
                     const int myr = have ? cidx[lane] : 0;
-                    double R[D];
-#pragma unroll
-                    for (int j = 0; j < D; ++j) R[j] = have ? Ht[static_cast<size_t>(j) * nrp + myr] : 0.0;
                     bool alive = have;
                     if (lane < D) yv[lane] = 0.0;
                     lds_fence();
@@ -608,9 +605,9 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
                         if (pick >= 2 * d + 8 || m >= d) break;
                         bool isw = false;
                         for (int a = 0; a < m; ++a) isw = isw || (widx[a] == myr);
-                        double gp = 0.0;
+                        double gp = 0.0;                        // (the candidate's row is read again per pick: D registers less)
 #pragma unroll
-                        for (int j = 0; j < D; ++j) gp = fma(R[j], pv[j], gp);
+                        for (int j = 0; j < D; ++j) gp = fma(Ht[static_cast<size_t>(j) * nrp + myr], pv[j], gp);
                         const double key = (alive && !isw) ? gp : -INFINITY;
                         const double wmax = wave_reduce<OpMax>(key);
                         if (!(wmax > 1e-13) || !(wmax > 1e-3 * pn_sel)) break;
