@@ -27,6 +27,7 @@ struct Variant {
     bool wave_ok = false;        // a compiled one-wave-per-QP shape covers this variant
     tmpc::DeviceQP db{};         // same model with Hs / Hinv padded for the block kernel
     tmpc::BlockQP bq{};
+    const tmpc::BlockArgs *bargs = nullptr;   // {db, bq} in device memory: what solve_block_kernel reads (tmpc_device.hpp)
     int tiles = 0;               // block kernel: NVP / 16 (0: not available)
     std::vector<void *> dev;     // device allocations of this variant
     std::vector<size_t> dev_bytes;       // their sizes (tmpc_debug_dump_layout)
@@ -330,6 +331,10 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         v.db.dbg = static_cast<long long *>(dbgp);
     }
 #endif
+    {
+        const tmpc::BlockArgs rec{v.db, v.bq};
+        if ((rc = upload(h, v, &rec, 1, &v.bargs))) return rc;
+    }
     return TMPC_OK;
 }
 
@@ -435,7 +440,7 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
             int rcw = ensure_block_ws(h);
             if (rcw) return rcw;
             // the workspace slices are sized for the largest variant; a slice is addressed with this variant's ncp
-            HIP_TRY(h, tmpc::launch_block(v.db, v.bq, v.tiles, h->blk_ws, h->blk_blocks, k, B, x_k, ref, variant, u_nom, x_nom0,
+            HIP_TRY(h, tmpc::launch_block(v.db, v.bq, v.bargs, v.tiles, h->blk_ws, h->blk_blocks, k, B, x_k, ref, variant, u_nom, x_nom0,
                                           xu_ss, x_nom, status, iters, h->stream));
             continue;
         }

@@ -41,6 +41,48 @@ namespace {
 
 using namespace wv;
 
+// The model record (BlockArgs) is read through the constant address space: every field is a scalar load at its point of use
+// (s_load from the scalar cache), not a register that has to survive the kernel.  ARGS_REFRESH() at the phase boundaries hands
+// the compiler an opaque copy of the record's address and of the workspace base, so that nothing derived from them is hoisted
+// out of the instance loop and kept alive across phases (the same device as TMPC_REFRESH() in tmpc_kernels.hip).
+// per-launch arguments of solve_block_kernel
+struct BlockLaunch {
+    const BlockArgs *args;
+    long long *ticks, *dbg;
+    double *ws;
+    int variant_id;
+    int64_t B;
+    const double *x_k, *ref;
+    const uint8_t *variant;
+    double *u_nom, *x_nom0, *xu_ss, *x_nom;
+    int32_t *status, *iters;
+};
+
+#ifdef TMPC_HOST_SIM
+typedef const BlockLaunch *LaunchPtr;
+typedef const BlockArgs *ArgsPtr;
+typedef const BlockQP CBlockQP;
+typedef const DeviceQP CDeviceQP;
+#define ARGS_REFRESH() do { } while (0)
+#else
+typedef const __attribute__((address_space(4))) BlockLaunch *LaunchPtr;
+typedef const __attribute__((address_space(4))) BlockArgs *ArgsPtr;
+typedef const __attribute__((address_space(4))) BlockQP CBlockQP;
+typedef const __attribute__((address_space(4))) DeviceQP CDeviceQP;
+// (through a vector register and v_readfirstlane: the compiler takes phase boundaries behind LDS-derived conditions for divergent
+// control flow and would not keep an "s"-constrained value in scalar registers there)
+__device__ __forceinline__ int fresh_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+template <class P>
+__device__ __forceinline__ P fresh_uniform(P p) {
+    unsigned lo = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)), hi = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return reinterpret_cast<P>((static_cast<uintptr_t>(hi) << 32) | lo);
+}
+#define ARGS_REFRESH() do { tid = fresh_lane(tid_k); lane = tid & (WAVE - 1); wave = tid >> 6; ap = (ArgsPtr)fresh_uniform(reinterpret_cast<const BlockArgs *>((uintptr_t)ap)); W0 = fresh_uniform(W0); lp = (LaunchPtr)fresh_uniform(reinterpret_cast<const BlockLaunch *>((uintptr_t)lp)); } while (0)
+#endif
+
 // threads per workgroup: 256 (4 waves, two workgroups per CU where the LDS allows) up to 64 variables; 512 (8 waves, one
 // workgroup per CU = two waves per SIMD) for the 128-variable shape, whose LDS footprint admits one workgroup only
 constexpr int block_threads(int tiles) { return tiles >= 8 ? 512 : 256; }
@@ -96,7 +138,7 @@ __device__ __forceinline__ double block_reduce1(double a, double *red, int wave,
 
 // G_row(r) . v for the thread's row: column-major copy, v in LDS (broadcast reads).  Eight loads in flight per
 // step: the operands come from L2, the loop is bound by how many of them are outstanding.
-__device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v, const BlockQP &bq) {
+__device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v, CBlockQP &bq) {
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     if (r < bq.nz4) {                      // initial-state row: znx columns only
         for (int a = 0; a < bq.znx; ++a) t0 = fma(Gcm[static_cast<size_t>(bq.zx0 + a) * ncp + r], v[bq.zx0 + a], t0);
@@ -117,7 +159,7 @@ __device__ __forceinline__ double row_dot(const double *__restrict__ Gcm, int nc
 
 // The same for the row pair (r, r + 1), r even: 16-byte loads (an 8-byte access runs at 0.54 - 0.70 of the 16-byte rate, and
 // the row passes sit at the CU's L1 rate).  Initial-state rows go through row_dot.
-__device__ __forceinline__ void row_dot2(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v, const BlockQP &bq,
+__device__ __forceinline__ void row_dot2(const double *__restrict__ Gcm, int ncp, int nv, int r, const double *v, CBlockQP &bq,
                                          double &o0, double &o1) {
     if (r < bq.nz4) { o0 = row_dot(Gcm, ncp, nv, r, v, bq); o1 = row_dot(Gcm, ncp, nv, r + 1, v, bq); return; }
     typedef double v2d __attribute__((ext_vector_type(2)));
@@ -183,7 +225,7 @@ __device__ __noinline__ double column_sums(const double *__restrict__ Hm, const 
 // out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
 template <int T>
 __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
-                                            double *parts, double *out_a, double *out_b, int tid, const BlockQP &bq) {
+                                            double *parts, double *out_a, double *out_b, int tid, CBlockQP &bq) {
     constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS, BT = BShape<T>::BT, NV2 = NVP / 2;
     typedef double v2d __attribute__((ext_vector_type(2)));
     // thread = (column pair, row part): 16-byte loads, a wave covers whole rows of G; the operands come from L2 or beyond
@@ -369,7 +411,7 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
 // znx x znx block (10 entries for the cart-pole instead of a pass of all 16-wide tiles over 850 rows).  Thread (pair p of
 // the lower triangle, row part q) sums d_r g_ra g_rb over its rows; the parts meet in LDS.
 template <int T>
-__device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm, const double *__restrict__ dvec, const BlockQP &bq,
+__device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm, const double *__restrict__ dvec, CBlockQP &bq,
                                                   double *M, double *parts, int tid) {
     if (bq.nz4 <= 0) return;
     constexpr int NVP = BShape<T>::NVP, LDM = BShape<T>::LDM, BT = BShape<T>::BT;
@@ -409,7 +451,7 @@ __device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm
 }
 
 template <int T>
-__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, const BlockQP &bq, int nsteps,
+__device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, CBlockQP &bq, int nsteps,
                                         double *M, int wave, int lane) {
     constexpr int G = BShape<T>::G;
     const int g = wave % G, rpart = wave / G;
@@ -446,7 +488,7 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
 // On return the strictly lower triangle of Mx holds L, dinv[j] = 1 / L[j][j].  Returns false (uniformly) on a
 // non-positive pivot.  Rows and columns >= n are never read as data (masked to zero / identity).
 template <int BWn>
-__device__ __noinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid ISTAMP_ARGS) {
+__device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *dinv, double *piv, int tid ISTAMP_ARGS) {
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -542,7 +584,7 @@ __device__ __noinline__ bool block_chol(double *Mx, int ld, int n, double *dinv,
 //   II.  the tiles below the diagonal are scaled by their row's diagonal inverse, Lt_ik = W_ii L_ik (MFMA);
 //   III. block diagonal d = 1, 2, ..: W_ij = - sum_{k = j}^{i-1} Lt_ik W_kj (MFMA), i - j = d; W_kj, k - j < d, is complete.
 template <int BWn>
-__device__ __noinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid ISTAMP_ARGS) {
+__device__ __forceinline__ void block_invert(double *Mx, int ld, int n, const double *dinv, int tid ISTAMP_ARGS) {
     const int lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nblk = (n + 15) >> 4;
     const int li = lane & 15, kq = lane >> 4;
@@ -689,21 +731,33 @@ __device__ __noinline__ void block_inv_solve(const double *Mx, int ld, int n, co
     __syncthreads();
 }
 
-// Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of workgroup 0, written to qp.dbg
+// Diagnostic build only (-DTMPC_STAMPS): per-phase cycle counts of workgroup 0, written to dbg_arg
 #ifdef TMPC_STAMPS
-#define BSTAMP(p) do { __syncthreads(); long long now_ = __builtin_amdgcn_s_memtime(); tph[p] += now_ - tlast; tlast = now_; } while (0)
+#define BSTAMP(p) do { ARGS_REFRESH(); __syncthreads(); long long now_ = __builtin_amdgcn_s_memtime(); tph[p] += now_ - tlast; tlast = now_; } while (0)
 #else
-#define BSTAMP(p) do { } while (0)
+#define BSTAMP(p) do { ARGS_REFRESH(); } while (0)      // phase boundary: nothing derived from the model record or the workspace base survives it
 #endif
 
 template <int T>
-__global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_kernel(
-    const DeviceQP qp, const BlockQP bq, double *__restrict__ ws, const int variant_id, const int64_t B,
-    const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
-    double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
-    double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters) {
+__global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_kernel(const BlockLaunch la) {
+    // The launch record is read where it is used, through the kernel-argument segment itself (constant address space), never
+    // through `la`: as by-value parameters its fifteen fields were loaded in the prologue and kept for the whole kernel.
+#ifdef TMPC_HOST_SIM
+    LaunchPtr lp = &la;
+#else
+    LaunchPtr lp = (LaunchPtr)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
+    const BlockArgs *const args = lp->args;
+
     using SH = BShape<T>;
     constexpr int NVP = SH::NVP, LDM = SH::LDM, WCAP = SH::WCAP, LDSS = SH::LDSS, BT = SH::BT;
+#ifdef TMPC_HOST_SIM
+    ArgsPtr ap = args;
+#else
+    ArgsPtr ap = (ArgsPtr)args;             // global -> constant address space: the record is read-only for every launch
+#endif
+#define qp (ap->qp)
+#define bq (ap->bq)
 #ifdef TMPC_HOST_SIM
     double *smem = sim::lds<double>();
 #else
@@ -729,29 +783,45 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
     double *red = xin + 32;                                          // [48] reductions (3 x 8 waves) | pivot | ints
     int *ibc = reinterpret_cast<int *>(red + 40);                    // a few ints
 
-    const int tid = threadIdx.x, lane = tid & (WAVE - 1), wave = tid >> 6;
+    // (tid and what follows from it -- LDS addresses, the masks of `tid < n` compares -- are re-derived at the phase boundaries too)
+    const int tid_k = threadIdx.x;
+    int tid = tid_k, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nv = qp.nv, nc = qp.nc, ncp = bq.ncp;
     const double *__restrict__ Grm = bq.Grm;
     const double *__restrict__ Gcm = bq.Gcm;
     const double *__restrict__ GHrm = bq.GHrm;
     const int nsteps = (nc + 3) / 4;
 
-    double *W0 = ws + static_cast<size_t>(blockIdx.x) * WS_COUNT * ncp;
-    double *s_ = W0 + WS_S * ncp, *lam_ = W0 + WS_LAM * ncp, *h_ = W0 + WS_H * ncp, *gz_ = W0 + WS_GZ * ncp;
-    double *rp_ = W0 + WS_RP * ncp, *d_ = W0 + WS_D * ncp, *v1_ = W0 + WS_V1 * ncp, *w_ = W0 + WS_W * ncp;
-    double *c1_ = W0 + WS_C1 * ncp, *rs_ = W0 + WS_RS * ncp, *ds_ = W0 + WS_DS * ncp, *dl_ = W0 + WS_DL * ncp;
-    double *gdz_ = W0 + WS_GDZ * ncp, *yall_ = W0 + WS_Y * ncp, *rr_ = W0 + WS_RR * ncp;
-    int *inW_ = reinterpret_cast<int *>(W0 + WS_INW * ncp);
+    // the sixteen workspace arrays are offsets of W0, formed where they are used (sixteen live pointers before)
+    double *W0 = lp->ws + static_cast<size_t>(blockIdx.x) * WS_COUNT * ncp;
+#define WSP(k) (W0 + static_cast<size_t>(k) * ncp)
+#define s_ WSP(WS_S)
+#define lam_ WSP(WS_LAM)
+#define h_ WSP(WS_H)
+#define gz_ WSP(WS_GZ)
+#define rp_ WSP(WS_RP)
+#define d_ WSP(WS_D)
+#define v1_ WSP(WS_V1)
+#define w_ WSP(WS_W)
+#define c1_ WSP(WS_C1)
+#define rs_ WSP(WS_RS)
+#define ds_ WSP(WS_DS)
+#define dl_ WSP(WS_DL)
+#define gdz_ WSP(WS_GDZ)
+#define yall_ WSP(WS_Y)
+#define rr_ WSP(WS_RR)
+#define inW_ (reinterpret_cast<int *>(WSP(WS_INW)))
 
-    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
-        if (variant != nullptr && variant[b] != variant_id) continue;
-        if (variant == nullptr && variant_id != 0) continue;
+    for (int64_t b = blockIdx.x; b < lp->B; b += gridDim.x) {
+        { const uint8_t *const variant = lp->variant; const int variant_id = lp->variant_id;
+          if (variant != nullptr && variant[b] != variant_id) continue;
+        if (variant == nullptr && variant_id != 0) continue; }
         __syncthreads();
-        if (tid < nx) { xin[tid] = x_k[b * nx + tid]; xin[16 + tid] = ref[b * nx + tid]; }
+        if (tid < nx) { xin[tid] = lp->x_k[b * nx + tid]; xin[16 + tid] = lp->ref[b * nx + tid]; }
         __syncthreads();
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
-        const long long t_begin = qp.ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
+        const long long t_begin = lp->ticks ? static_cast<long long>(__builtin_amdgcn_s_memrealtime()) : 0;
 #ifdef TMPC_STAMPS
         long long tph[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         long long tlast = __builtin_amdgcn_s_memtime();
@@ -1162,18 +1232,18 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
             tv[tid] = (tid < nv) ? qp.Dv[tid] * zv[tid] : 0.0;     // unscaled z
         }
         __syncthreads();
-        for (int i = tid; i < N * nu; i += BT) u_nom[b * N * nu + i] = good ? zo[i] : nanv;
-        if (tid < nx + nu && xu_ss) {
+        for (int i = tid; i < N * nu; i += BT) lp->u_nom[b * N * nu + i] = good ? zo[i] : nanv;
+        if (tid < nx + nu && lp->xu_ss) {
             double v = 0.0;
             for (int j = 0; j < qp.nth; ++j) v += qp.Mth[tid * qp.nth + j] * zo[qp.off_theta + j];
-            xu_ss[b * (nx + nu) + tid] = good ? v : nanv;
+            lp->xu_ss[b * (nx + nu) + tid] = good ? v : nanv;
         }
         if (tid < nx) {
             const double x0 = (qp.off_x0 >= 0) ? zo[qp.off_x0 + tid] : xin[tid];
-            if (x_nom0) x_nom0[b * nx + tid] = good ? x0 : nanv;
+            if (lp->x_nom0) lp->x_nom0[b * nx + tid] = good ? x0 : nanv;
             uv[tid] = x0;
         }
-        if (x_nom) {
+        if (double *const x_nom = lp->x_nom) {
             __syncthreads();
             if (tid < nx) x_nom[b * (N + 1) * nx + tid] = good ? uv[tid] : nanv;
             for (int i = 0; i < N; ++i) {
@@ -1187,29 +1257,49 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                 __syncthreads();
             }
         }
-        if (tid == 0) { status[b] = st; iters[b] = it_done; }
-        if (qp.ticks && tid == 0) qp.ticks[b] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()) - t_begin;
+        if (tid == 0) { lp->status[b] = st; lp->iters[b] = it_done; }
+        if (lp->ticks && tid == 0) lp->ticks[b] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()) - t_begin;
 #ifdef TMPC_STAMPS
         BSTAMP(11);
-        if (blockIdx.x == 0 && tid == 0 && qp.dbg && it_done > 0) { for (int p_ = 0; p_ < 16; ++p_) qp.dbg[p_] = tph[p_]; }
+        if (blockIdx.x == 0 && tid == 0 && lp->dbg && it_done > 0) { for (int p_ = 0; p_ < 16; ++p_) lp->dbg[p_] = tph[p_]; }
 #endif
     }
 }
+#undef qp
+#undef bq
+#undef WSP
+#undef s_
+#undef lam_
+#undef h_
+#undef gz_
+#undef rp_
+#undef d_
+#undef v1_
+#undef w_
+#undef c1_
+#undef rs_
+#undef ds_
+#undef dl_
+#undef gdz_
+#undef yall_
+#undef rr_
+#undef inW_
 
 #ifdef TMPC_HOST_SIM
 unsigned long sim_rendezvous_total = 0;
 // tests/wavesim: one workgroup on the host execution model takes the whole batch (grid of one)
 template <int T>
-hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int ws_blocks, int variant_id, int64_t B,
+hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, double *ws, int ws_blocks, int variant_id, int64_t B,
                           const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                           double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
     constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
     static_assert(lds <= 160 * 1024, "block shape does not fit the 160 KiB LDS of a CU");
-    (void)ws_blocks; (void)stream;
+    (void)ws_blocks; (void)stream; (void)dargs;
+    const BlockArgs host_args{qp, bq};
     sim::Dim3 bi, gd;
     bi.x = bi.y = bi.z = 0;
     sim_rendezvous_total += sim::run_block(BShape<T>::BT, lds, bi, gd, [&]() {
-        solve_block_kernel<T>(qp, bq, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
+        solve_block_kernel<T>(BlockLaunch{&host_args, qp.ticks, qp.dbg, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters});
     });
     return hipSuccess;
 }
@@ -1217,7 +1307,7 @@ template <int T>
 int block_occupancy_t() { return 1; }
 #else
 template <int T>
-hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int ws_blocks, int variant_id, int64_t B,
+hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, double *ws, int ws_blocks, int variant_id, int64_t B,
                           const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                           double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
     constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
@@ -1231,10 +1321,12 @@ hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, double *ws, int
         if (e != hipSuccess) return e;
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id].store(true, std::memory_order_release);
     }
+    if (dargs == nullptr) return hipErrorInvalidValue;
+    (void)bq;
     int64_t blocks = B < ws_blocks ? B : ws_blocks;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL((solve_block_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(BShape<T>::BT), lds, stream, qp, bq, ws, variant_id, B,
-                       x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters);
+    hipLaunchKernelGGL((solve_block_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(BShape<T>::BT), lds, stream,
+                       BlockLaunch{dargs, qp.ticks, qp.dbg, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters});
     return hipGetLastError();
 }
 
@@ -1285,14 +1377,14 @@ int block_occupancy(int tiles) {
     return 1;
 }
 
-hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
+hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
     switch (tiles) {
-        case 1: return launch_block_t<1>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
-        case 2: return launch_block_t<2>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
-        case 4: return launch_block_t<4>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
-        case 8: return launch_block_t<8>(qp, bq, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 1: return launch_block_t<1>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 2: return launch_block_t<2>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 4: return launch_block_t<4>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 8: return launch_block_t<8>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
     }
     return hipErrorInvalidValue;
 }

@@ -69,6 +69,15 @@ struct BlockQP {
     int row_start[9];     // row_start[t]: first row that reaches the 16-column tile t (row_start[0] = nz4; nc if none)
 };
 
+// What solve_block_kernel reads of the model: one record in device memory per variant (written once by tmpc_create), handed
+// to the kernel as ONE pointer.  By value the two structures were sixty kernel-argument pointers that stayed live through the
+// whole kernel: they overflowed the scalar registers into vector lanes and from there into scratch (round 2: 89 spilled VGPRs,
+// 480 B private segment).  Read through the constant address space, a field costs a scalar load where it is used.
+struct BlockArgs {
+    DeviceQP qp;          // (qp.ticks / qp.dbg of this copy are not used: they change per launch and travel as kernel arguments)
+    BlockQP bq;
+};
+
 struct KernelShape {
     int nvp = 0, dp = 0, ds = 0, kcp = 0, cp = 0, cs = 0;
 };
@@ -99,7 +108,8 @@ int block_tiles(int nv);
 int block_workspace_rows();
 size_t block_lds_bytes(int tiles);
 int block_occupancy(int tiles);
-hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
+// dargs: the device copy of {qp, bq} (unused on the host execution model of tests/wavesim, which reads qp / bq directly)
+hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream);
 

@@ -60,7 +60,7 @@ int main(int argc, char **argv) {
     std::unique_ptr<int32_t[]> st(new int32_t[b]), it(new int32_t[b]);
     // the per-workgroup workspace: uninitialised on purpose
     std::unique_ptr<double[]> ws(new double[static_cast<size_t>(tmpc::block_workspace_rows()) * bq.ncp]);
-    const hipError_t e = tmpc::launch_block(d, bq, hd[0], ws.get(), 1, 0, B, xk.data(), ref.data(), nullptr, u.get(), x0.get(), ss.get(), nullptr,
+    const hipError_t e = tmpc::launch_block(d, bq, nullptr, hd[0], ws.get(), 1, 0, B, xk.data(), ref.data(), nullptr, u.get(), x0.get(), ss.get(), nullptr,
                                            st.get(), it.get(), nullptr);
     need(e == hipSuccess, "launch failed");
     std::fprintf(stderr, "blocksim: tmpc::solve_block_kernel<%d>, %lld instances\n", hd[0], static_cast<long long>(B));
