@@ -271,41 +271,65 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const tmpc::Condensed &c = v.c;
     v.tiles = tmpc::block_tiles(c.nv);
     if (v.tiles == 0) return TMPC_OK;
-    const int NVP = 16 * v.tiles, nx = c.nx, ncp = (c.nc + 63) / 64 * 64;
-    std::vector<double> Grm(static_cast<size_t>(ncp) * NVP, 0.0), Gcm(Grm.size(), 0.0), GH(Grm.size(), 0.0), g0(ncp, 1.0),
-        Es(static_cast<size_t>(ncp) * nx, 0.0);
+    const int NVP = 16 * v.tiles, nx = c.nx;
     // the Z rows of a free initial state touch x_0 only: the block kernel treats them as a narrow class when there are many
     const int nz4 = (c.off_x0 >= 0 && c.nz >= 256) ? (c.nz / 4) * 4 : 0;
+    // Functionals (tmpc_device.hpp, BlockQP): when every row has its mirror row (the two sides of a box-type constraint; exact
+    // to 1e-13 after scaling, Condensed::mirror) a row of G serves both, and the G-sized passes read half the rows.
+    // TMPC_BLOCK_PAIRS=0 (developer knob) keeps a row of G per constraint row.
+    bool paired = nz4 == 0 && c.nc >= 2 && static_cast<int>(c.mirror.size()) == c.nc;
+    for (int r = 0; paired && r < c.nc; ++r) paired = c.mirror[r] >= 0 && c.mirror[r] < c.nc && c.mirror[r] != r && c.mirror[c.mirror[r]] == r;
+    if (const char *e = std::getenv("TMPC_BLOCK_PAIRS")) paired = paired && std::atoi(e) != 0;
+    // rows of G: constraint rows, or the first member of every pair
+    std::vector<int> grow;
+    for (int r = 0; r < c.nc; ++r)
+        if (!paired || c.mirror[r] > r) grow.push_back(r);
+    const int ng = static_cast<int>(grow.size()), ngp = (ng + 63) / 64 * 64;
+    const int mir = paired ? ngp : 0, ncp = paired ? 2 * ngp : ngp;
     // Staircase of the condensed constraints: the rows of stage k act on u_0 .. u_k only, so the leading rows of G are
     // zero beyond a few 16-column tiles.  The general rows are ordered by the number of tiles they reach (stable), and the
     // kernel skips the tiles / columns a row does not touch (exact: the skipped entries are zero).
-    std::vector<int> ext(c.nc, 1), order(c.nc);
-    for (int r = 0; r < c.nc; ++r) {
+    std::vector<int> ext(ng, 1), order(ng);
+    for (int k = 0; k < ng; ++k) {
         int last = 0;
         for (int j = 0; j < c.nv; ++j)
-            if (c.Gs(r, j) != 0.0) last = j;
-        ext[r] = last / 16 + 1;
-        order[r] = r;
+            if (c.Gs(grow[k], j) != 0.0) last = j;
+        ext[k] = last / 16 + 1;
+        order[k] = k;
     }
     std::stable_sort(order.begin() + nz4, order.end(), [&](int a, int b) { return ext[a] < ext[b]; });
-    std::vector<int32_t> ncols(ncp, c.nv);
-    for (int t = 0; t <= 8; ++t) v.bq.row_start[t] = c.nc;
-    for (int rr = c.nc - 1; rr >= nz4; --rr)
+    std::vector<double> Grm(static_cast<size_t>(ngp) * NVP, 0.0), Gcm(Grm.size(), 0.0), g0(ncp, 1.0), Es(static_cast<size_t>(ncp) * nx, 0.0);
+    std::vector<double> Gw(paired ? static_cast<size_t>(ncp) * NVP : 0, 0.0), GH(static_cast<size_t>(ncp) * NVP, 0.0);
+    std::vector<int32_t> ncols(ngp, c.nv);
+    for (int t = 0; t <= 8; ++t) v.bq.row_start[t] = ng;
+    for (int rr = ng - 1; rr >= nz4; --rr)
         for (int t = 0; t < ext[order[rr]] && t <= 8; ++t) v.bq.row_start[t] = rr;
     v.bq.row_start[0] = nz4;
-    for (int rr = 0; rr < c.nc; ++rr) {
-        const int r = order[rr];
-        ncols[rr] = rr < nz4 ? c.nv : std::min(c.nv, 16 * ext[r]);
+    for (int rr = 0; rr < ng; ++rr) {
+        const int r = grow[order[rr]];
+        ncols[rr] = rr < nz4 ? c.nv : std::min(c.nv, 16 * ext[order[rr]]);
         for (int j = 0; j < c.nv; ++j) {
             const double g = c.Gs(r, j);
             Grm[static_cast<size_t>(rr) * NVP + j] = g;
-            Gcm[static_cast<size_t>(j) * ncp + rr] = g;
+            Gcm[static_cast<size_t>(j) * ngp + rr] = g;
             double t = 0.0;
             for (int k = 0; k < c.nv; ++k) t += c.Gs(r, k) * c.Hinv(k, j);
             GH[static_cast<size_t>(rr) * NVP + j] = t;
+            if (paired) {
+                // the lower side is the negated functional (not the mirror row's own entries, which agree to 1e-13): every
+                // pass sees the same row
+                Gw[static_cast<size_t>(rr) * NVP + j] = g;
+                Gw[static_cast<size_t>(rr + mir) * NVP + j] = -g;
+                GH[static_cast<size_t>(rr + mir) * NVP + j] = -t;
+            }
         }
         g0[rr] = c.g0s[r];
         for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(rr) * nx + j] = c.Es(r, j);
+        if (paired) {
+            const int q = c.mirror[r];
+            g0[rr + mir] = c.g0s[q];
+            for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(rr + mir) * nx + j] = c.Es(q, j);
+        }
     }
     int rc;
     if ((rc = upload_common(h, v, p, v.db, NVP))) return rc;
@@ -316,8 +340,11 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     v.bq.nz4 = nz4;
     v.bq.zx0 = c.off_x0 >= 0 ? c.off_x0 : 0;
     v.bq.znx = nx;
+    v.bq.mir = mir; v.bq.ng = ng; v.bq.ngp = ngp;
     if ((rc = upload(h, v, Grm.data(), Grm.size(), &v.bq.Grm))) return rc;
     if ((rc = upload(h, v, Gcm.data(), Gcm.size(), &v.bq.Gcm))) return rc;
+    if (paired) { if ((rc = upload(h, v, Gw.data(), Gw.size(), &v.bq.Gw))) return rc; }
+    else v.bq.Gw = v.bq.Grm;
     if ((rc = upload(h, v, GH.data(), GH.size(), &v.bq.GHrm))) return rc;
     if ((rc = upload(h, v, g0.data(), g0.size(), &v.bq.g0))) return rc;
     if ((rc = upload(h, v, Es.data(), Es.size(), &v.bq.Es))) return rc;
@@ -686,7 +713,7 @@ int tmpc_debug_dump_block_layout(const tmpc_handle *h, int variant, const char *
     std::fwrite(&v.db, sizeof(tmpc::DeviceQP), 1, f);
     std::fwrite(&v.bq, sizeof(tmpc::BlockQP), 1, f);
     const void *ptrs[] = {v.db.Hs, v.db.Hinv, v.db.F1s, v.db.F2s, v.db.gp0, v.db.Ep, v.db.Dv, v.db.Tzs, v.db.Txf, v.db.Mth, v.db.A, v.db.B,
-                          v.bq.Grm, v.bq.Gcm, v.bq.GHrm, v.bq.g0, v.bq.Es, v.bq.ncols};
+                          v.bq.Grm, v.bq.Gcm, v.bq.GHrm, v.bq.g0, v.bq.Es, v.bq.ncols, v.bq.Gw == v.bq.Grm ? nullptr : v.bq.Gw};
     for (const void *q : ptrs) {
         uint64_t n = 0;
         if (q)

@@ -235,13 +235,15 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
     const v2d *__restrict__ G2 = reinterpret_cast<const v2d *>(Grm) + j2;
     const int rs = bq.row_start[(2 * j2) >> 4];   // rows below do not reach this column tile (staircase): not loaded
     const v2d zero2 = {0.0, 0.0};
+    const int mir = bq.mir;                // != 0: row r of G is a functional, its weight is va[r] - va[r + mir] (BlockQP)
+    auto wt = [&](const double *w, int row) { return mir != 0 ? w[row] - w[row + mir] : w[row]; };
     int r = bq.nz4 + part;                 // general rows; the initial-state rows [0, nz4) follow below
     if constexpr (NV2 >= WAVE) {
         // a wave = one row part (T = 8): sixteen rows per trip, their weights va / vb fetched by sixteen lanes in one gather each
         // and handed round by v_readlane (a load per row and lane would triple the vector-memory instructions of the pass)
         for (; r + 15 * PARTS < nc; r += 16 * PARTS) {
             const int rl = r + (tid & 15) * PARTS;
-            const double xal = va[rl], xbl = vb[rl];
+            const double xal = wt(va, rl), xbl = wt(vb, rl);
             v2d g[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
@@ -259,8 +261,8 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
-                xa[k] = va[r + k * PARTS];
-                xb[k] = vb[r + k * PARTS];
+                xa[k] = wt(va, r + k * PARTS);
+                xb[k] = wt(vb, r + k * PARTS);
             }
 #pragma unroll
             for (int k = 0; k < 8; k += 2) {
@@ -271,7 +273,7 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
     }
     for (; r < nc; r += PARTS) {
         const v2d g0 = (r >= rs) ? G2[static_cast<size_t>(r) * NV2] : zero2;
-        a0 += g0 * va[r]; b0 += g0 * vb[r];
+        a0 += g0 * wt(va, r); b0 += g0 * wt(vb, r);
     }
     __syncthreads();                       // previous readers of `parts` are done
     a0 += a1; b0 += b1;
@@ -330,7 +332,7 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
 // the tiles of row RA alone and [ksB, nsteps) for both rows.
 template <int T, int RA, int RB>
 __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int ksA, int ksB, int nsteps,
-                                          int rpart, double *M, int lane) {
+                                          int rpart, double *M, int lane, int mir) {
     using SH = BShape<T>;
     constexpr int NVP = SH::NVP, LDM = SH::LDM, RS = SH::RSPLIT;
     constexpr int NA = RA + 1, NB = RB + 1;
@@ -357,7 +359,8 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
                 const size_t row = static_cast<size_t>(4 * (in ? ks : ks_begin) + kq);
 #pragma unroll
                 for (int t = 0; t < NL; ++t) g[u][t] = Grm[row * NVP + 16 * t + c];
-                dv[u] = in ? dvec[row] : 0.0;
+                // (mir != 0: the row is a functional, its weight the sum of its two sides' -- BlockQP)
+                dv[u] = in ? (mir != 0 ? dvec[row] + dvec[row + mir] : dvec[row]) : 0.0;
             }
         };
         int ks = ks_begin + rpart;
@@ -456,18 +459,19 @@ __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const do
     constexpr int G = BShape<T>::G;
     const int g = wave % G, rpart = wave / G;
     const int ks0 = bq.nz4 / 4;                    // k-steps below belong to the initial-state rows (handled apart)
+    const int mir = bq.mir;
     auto first = [&](int t) { const int k = bq.row_start[t] / 4; return k > ks0 ? k : ks0; };
     if constexpr (G == 1) {
-        if constexpr (T == 1) gdg_group<T, -1, 0>(Grm, dvec, ks0, ks0, nsteps, rpart, M, lane);
-        else gdg_group<T, 0, 1>(Grm, dvec, first(0), first(1), nsteps, rpart, M, lane);
+        if constexpr (T == 1) gdg_group<T, -1, 0>(Grm, dvec, ks0, ks0, nsteps, rpart, M, lane, mir);
+        else gdg_group<T, 0, 1>(Grm, dvec, first(0), first(1), nsteps, rpart, M, lane, mir);
     } else if constexpr (G == 2) {
-        if (g == 0) gdg_group<T, 0, 3>(Grm, dvec, first(0), first(3), nsteps, rpart, M, lane);
-        else gdg_group<T, 1, 2>(Grm, dvec, first(1), first(2), nsteps, rpart, M, lane);
+        if (g == 0) gdg_group<T, 0, 3>(Grm, dvec, first(0), first(3), nsteps, rpart, M, lane, mir);
+        else gdg_group<T, 1, 2>(Grm, dvec, first(1), first(2), nsteps, rpart, M, lane, mir);
     } else {
-        if (g == 0) gdg_group<T, 0, 7>(Grm, dvec, first(0), first(7), nsteps, rpart, M, lane);
-        else if (g == 1) gdg_group<T, 1, 6>(Grm, dvec, first(1), first(6), nsteps, rpart, M, lane);
-        else if (g == 2) gdg_group<T, 2, 5>(Grm, dvec, first(2), first(5), nsteps, rpart, M, lane);
-        else gdg_group<T, 3, 4>(Grm, dvec, first(3), first(4), nsteps, rpart, M, lane);
+        if (g == 0) gdg_group<T, 0, 7>(Grm, dvec, first(0), first(7), nsteps, rpart, M, lane, mir);
+        else if (g == 1) gdg_group<T, 1, 6>(Grm, dvec, first(1), first(6), nsteps, rpart, M, lane, mir);
+        else if (g == 2) gdg_group<T, 2, 5>(Grm, dvec, first(2), first(5), nsteps, rpart, M, lane, mir);
+        else gdg_group<T, 3, 4>(Grm, dvec, first(3), first(4), nsteps, rpart, M, lane, mir);
     }
 }
 
@@ -787,10 +791,25 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
     const int tid_k = threadIdx.x;
     int tid = tid_k, lane = tid & (WAVE - 1), wave = tid >> 6;
     const int nx = qp.nx, nu = qp.nu, N = qp.N, nv = qp.nv, nc = qp.nc, ncp = bq.ncp;
+    // Rows of G and rows of the problem (BlockQP): with mir != 0 a row of G is a FUNCTIONAL g, serving the constraint rows r
+    // (g'z <= h_r) and r + mir (-g'z <= h_{r+mir}); every pass over G then runs over ng = nc / 2 rows.  mir == 0: ng == nc.
+    const int mir = bq.mir, ng = bq.ng, ngp = bq.ngp;
     const double *__restrict__ Grm = bq.Grm;
     const double *__restrict__ Gcm = bq.Gcm;
     const double *__restrict__ GHrm = bq.GHrm;
-    const int nsteps = (nc + 3) / 4;
+    const double *__restrict__ Gw = bq.Gw;
+    const int nsteps = (ng + 3) / 4;
+    auto valid_row = [&](int r) { return ((mir != 0 && r >= mir) ? r - mir : r) < ng; };
+    // G v for every row: pairs of rows of G (16-byte loads, row_dot2), the mirror rows take the negated product
+    auto row_products = [&](const double *vec, auto &&body) {
+        for (int f2 = 2 * tid; f2 < ngp; f2 += 2 * BT) {
+            double p0, p1;
+            row_dot2(Gcm, ngp, nv, f2, vec, bq, p0, p1);
+            body(f2, p0);
+            body(f2 + 1, p1);
+            if (mir != 0) { body(f2 + mir, -p0); body(f2 + 1 + mir, -p1); }
+        }
+    };
 
     // the sixteen workspace arrays are offsets of W0, formed where they are used (sixteen live pointers before)
     double *W0 = lp->ws + static_cast<size_t>(blockIdx.x) * WS_COUNT * ncp;
@@ -848,7 +867,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
             double v = bq.g0[r];
             for (int c = 0; c < nx; ++c) v += bq.Es[static_cast<size_t>(r) * nx + c] * xin[c];
             h_[r] = v;
-            if (r < nc) hn_l = fmax(hn_l, fabs(v));
+            if (valid_row(r)) hn_l = fmax(hn_l, fabs(v));
         }
         __syncthreads();
         // z = -Hinv q (Hinv symmetric: column read = coalesced)
@@ -858,19 +877,13 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
         }
         __syncthreads();
         double smin_l = INFINITY;
-        for (int r2 = 2 * tid; r2 < ncp; r2 += 2 * BT) {            // row pairs (row_dot2)
-            double gzp[2];
-            row_dot2(Gcm, ncp, nv, r2, zv, bq, gzp[0], gzp[1]);
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r = r2 + q;
-                const double sv = h_[r] - gzp[q];
-                gz_[r] = gzp[q];
-                s_[r] = sv;
-                lam_[r] = 0.0;
-                if (r < nc) smin_l = fmin(smin_l, sv);
-            }
-        }
+        row_products(zv, [&](int r, double gzr) {
+            const double sv = h_[r] - gzr;
+            gz_[r] = gzr;
+            s_[r] = sv;
+            lam_[r] = 0.0;
+            if (valid_row(r)) smin_l = fmin(smin_l, sv);
+        });
         block_reduce3<SH::BW, OpMax, OpMax, OpMin>(qn_l, hn_l, smin_l, red, wave, lane);
         const double qn = qn_l, hn = hn_l, smin = smin_l;
         BSTAMP(0);
@@ -884,7 +897,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
             {
                 const double fl = 0.1 * fmax(-smin, 1.0);
                 for (int r = tid; r < ncp; r += BT) {
-                    const bool valid = r < nc;
+                    const bool valid = valid_row(r);
                     s_[r] = valid ? fmax(s_[r], fl) : 1.0;
                     lam_[r] = valid ? 1.0 : 0.0;
                 }
@@ -901,7 +914,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     // ---- P1: residuals and scalings per row
                     double gap = 0.0, rpn = 0.0, lmax = 0.0;
                     for (int r = tid; r < ncp; r += BT) {
-                        const bool valid = r < nc;
+                        const bool valid = valid_row(r);
                         const double sv = s_[r], lv = lam_[r];
                         const double rp = gz_[r] + sv - h_[r];
                         const double rs = valid ? fast_rcp(sv) : 0.0;
@@ -921,7 +934,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         const double v = column_sums<T>(qp.Hs, zv, nullptr, nullptr, nullptr, 0, parts, tid);
                         if (tid < NVP) cgv[tid] = qv[tid] + v;
                     }
-                    gt_products<T>(Grm, nc, lam_, v1_, parts, glv, tv, tid, bq);
+                    gt_products<T>(Grm, ng, lam_, v1_, parts, glv, tv, tid, bq);
                     double rdn = 0.0, obj = 0.0, gln = 0.0;
                     if (tid < NVP) {
                         const double cgj = cgv[tid], qj = qv[tid];
@@ -944,7 +957,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     }
                     if (lmax > 1e10) {
                         double hl = 0.0;
-                        for (int r = tid; r < nc; r += BT) hl += h_[r] * lam_[r];
+                        for (int r = tid; r < ncp; r += BT) hl += h_[r] * lam_[r];          // (padding rows: lambda = 0)
                         hl = block_reduce1<SH::BW, OpSum>(hl, red, wave, lane);
                         if (hl < 0.0 && gln <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
                     }
@@ -973,7 +986,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             double trc = 0.0;
                             for (int i = 0; i < nv; ++i) trc += qp.Hs[i * NVP + i];
                             double dsum = 0.0;
-                            for (int r = tid; r < nc; r += BT) dsum += d_[r];
+                            for (int r = tid; r < ncp; r += BT) dsum += d_[r];                // (padding rows: d = 0)
                             dsum = block_reduce1<SH::BW, OpSum>(dsum, red, wave, lane);
                             shift = 1e-13 * (trc + dsum);
                         }
@@ -990,7 +1003,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     // ---- P5: affine step statistics, corrector terms per row
                     double rho_aff = 0.0, sb1 = 0.0, sb2 = 0.0;
                     auto p5_row = [&](int r, double gd) {
-                        const bool valid = r < nc;
+                        const bool valid = valid_row(r);
                         const double sv = s_[r], lv = lam_[r], rp = rp_[r], d = d_[r];
                         const double rs = valid ? fast_rcp(sv) : 0.0;
                         const double dsa = valid ? (-rp - gd) : 0.0;
@@ -1004,12 +1017,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         c1_[r] = w * rs;
                         rs_[r] = rs;
                     };
-                    for (int r = 2 * tid; r < ncp; r += 2 * BT) {            // row pairs (ncp is a multiple of 64)
-                        double gd0, gd1;
-                        row_dot2(Gcm, ncp, nv, r, dzav, bq, gd0, gd1);
-                        p5_row(r, gd0);
-                        p5_row(r + 1, gd1);
-                    }
+                    row_products(dzav, p5_row);
                     block_reduce3<SH::BW, OpMax, OpSum, OpSum>(rho_aff, sb1, sb2, red, wave, lane);
                     const double aaff = rho_aff > 1.0 ? 1.0 / rho_aff : 1.0;
                     const double mu_aff = (gap + aaff * sb1 + aaff * aaff * sb2) / ncd;
@@ -1018,7 +1026,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     const double smu = sigma * mu;
                     BSTAMP(7);
                     // ---- P6: corrector right-hand side and solve
-                    gt_products<T>(Grm, nc, c1_, rs_, parts, tv, uv, tid, bq);
+                    gt_products<T>(Grm, ng, c1_, rs_, parts, tv, uv, tid, bq);
                     if (tid < NVP) cgv[tid] = rhsv[tid] + tv[tid] - smu * uv[tid];
                     __syncthreads();
                     block_inv_solve<BT>(big, LDM, nv, dinv, cgv, dzv, parts, tid, NVP);
@@ -1029,7 +1037,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     const double tau = 1.0 - om;
                     double rho = 0.0;
                     auto p7_row = [&](int r, double gd) {
-                        const bool valid = r < nc;
+                        const bool valid = valid_row(r);
                         const double sv = s_[r], lv = lam_[r], rp = rp_[r], rs = rs_[r];
                         const double dsk = valid ? (-rp - gd) : 0.0;
                         const double rc = sv * lv + w_[r] - smu;
@@ -1040,12 +1048,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         ds_[r] = dsk;
                         dl_[r] = dlk;
                     };
-                    for (int r = 2 * tid; r < ncp; r += 2 * BT) {
-                        double gd0, gd1;
-                        row_dot2(Gcm, ncp, nv, r, dzv, bq, gd0, gd1);
-                        p7_row(r, gd0);
-                        p7_row(r + 1, gd1);
-                    }
+                    row_products(dzv, p7_row);
                     rho = block_reduce1<SH::BW, OpMax>(rho, red, wave, lane);
                     const double alpha = rho > tau ? tau / rho : 1.0;
                     // ---- P8: update
@@ -1066,7 +1069,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     double *S = big;
                     for (int r = tid; r < ncp; r += BT) {
                         const double lv = lam_[r];
-                        inW_[r] = (r < nc && lv > s_[r]) ? 1 : 0;
+                        inW_[r] = (valid_row(r) && lv > s_[r]) ? 1 : 0;
                         yall_[r] = lv;
                     }
                     if (tid < NVP) zpv[tid] = zv[tid];
@@ -1098,7 +1101,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                                 const int a = idx / m, c2 = idx - a * m;
                                 if (c2 > a) continue;
                                 const double *ga = GHrm + static_cast<size_t>(Widx[a]) * NVP;
-                                const double *gc = Grm + static_cast<size_t>(Widx[c2]) * NVP;
+                                const double *gc = Gw + static_cast<size_t>(Widx[c2]) * NVP;
                                 double v0 = 0.0, v1 = 0.0;
                                 #pragma unroll 4
             for (int j = 0; j + 1 < NVP; j += 2) { v0 = fma(ga[j], gc[j], v0); v1 = fma(ga[j + 1], gc[j + 1], v1); }
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             for (int stp = 0; stp < 12; ++stp) {      // (nearly parallel working rows need more than the usual two)
                                 // r1 = Hs zp + q + G_W' y
                                 {
-                                    const double v = column_sums<T>(qp.Hs, zpv, Grm, Widx, yv, m, parts, tid);
+                                    const double v = column_sums<T>(qp.Hs, zpv, Gw, Widx, yv, m, parts, tid);
                                     if (tid < NVP) tv[tid] = qv[tid] + v;
                                 }
                                 __syncthreads();
@@ -1127,7 +1130,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                                 // dy rhs: (G_W zp - h_W) - G_W t1
                                 if (tid < m) {
                                     const int r = Widx[tid];
-                                    const double *g = Grm + static_cast<size_t>(r) * NVP;
+                                    const double *g = Gw + static_cast<size_t>(r) * NVP;
                                     double gz = 0.0, gt = 0.0;
 #pragma unroll 8
                                     for (int j = 0; j < NVP; ++j) { gz = fma(g[j], zpv[j], gz); gt = fma(g[j], uv[j], gt); }
@@ -1162,15 +1165,11 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         if (tid < m) yall_[Widx[tid]] = yv[tid];
                         __syncthreads();
                         double nviol = 0.0, nneg = 0.0, nloose = 0.0;
-                        for (int r2 = 2 * tid; r2 < ncp; r2 += 2 * BT) {
-                          double gzp[2];
-                          row_dot2(Gcm, ncp, nv, r2, zpv, bq, gzp[0], gzp[1]);
-#pragma unroll
-                          for (int q = 0; q < 2; ++q) {
-                            const int r = r2 + q;
-                            const bool valid = r < nc;
+                        row_products(zpv, [&](int r, double gzr) {
+                          {
+                            const bool valid = valid_row(r);
                             const double hk = h_[r];
-                            const double rr = gzp[q] - hk;
+                            const double rr = gzr - hk;
                             rr_[r] = rr;
                             const bool in = inW_[r] != 0;
                             const double hi = fmax(fabs(hk), 1.0);
@@ -1183,7 +1182,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                             if (neg) { inW_[r] = 0; yall_[r] = 0.0; }
                             if (viol) { inW_[r] = 1; yall_[r] = 0.0; }
                           }
-                        }
+                        });
                         block_reduce3<SH::BW, OpSum, OpSum, OpSum>(nviol, nneg, nloose, red, wave, lane);
                         // rows of W off their bound with nothing left to correct: not converged, give up (see tmpc_kernels.hip)
                         if (nloose != 0.0 && nviol == 0.0 && nneg == 0.0) {

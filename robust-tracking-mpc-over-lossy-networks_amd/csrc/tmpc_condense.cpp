@@ -429,7 +429,7 @@ std::string condense(const tmpc_problem &p, int variant, Condensed &out) {
     }
     // mirror rows (the two sides of box-type constraints), within the dense class and within the factored class
     c.mirror.assign(c.nc, -1);
-    if (nv <= 32) {
+    {
         auto in_fact = [&](int r) { return c.ncc > 0 && r >= c.fb0 && r < c.fb0 + c.ncc; };
         for (int r = 0; r < c.nc; ++r) {
             if (c.mirror[r] >= 0) continue;

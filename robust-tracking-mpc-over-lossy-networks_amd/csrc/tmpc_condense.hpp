@@ -60,7 +60,7 @@ struct Condensed {
     Mat Psi;     // kc x nv, scaled with Dv
     Mat Hc;      // ncc x kc, rows scaled like Gs
     // mirror[r] = q when scaled row q is the exact mirror image of row r (Gs_q = -Gs_r: the two sides of a box-type
-    // constraint) and both lie in the same class (dense / factored); -1 otherwise.  Filled for nv <= 32 only.
+    // constraint) and both lie in the same class (dense / factored); -1 otherwise.
     std::vector<int> mirror;
 };
 

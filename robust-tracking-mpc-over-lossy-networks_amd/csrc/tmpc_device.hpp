@@ -56,17 +56,27 @@ struct DeviceQP {
     long long *ticks;     // [B] or nullptr: time the instance spent in its wave / workgroup, in s_memrealtime ticks (10 ns)
 };
 
-// Block path (tmpc_block.hip): all rows dense, row order of Condensed::Gs, nv padded to 16 * tiles
+// Block path (tmpc_block.hip): all rows dense, nv padded to 16 * tiles.
+//
+// Two layouts.  mir == 0: a row of G per constraint row, in the order of Condensed::Gs (initial-state rows first, the general
+// rows by the column tiles they reach).  mir != 0 (every row has its mirror row, Condensed::mirror: box-type sets and sets
+// derived from them, which is what the reference builds): a row of G per FUNCTIONAL g; the per-row arrays (g0, Es, the
+// kernel's workspace) hold its upper side g'z <= h at index f and its lower side -g'z <= h at index f + mir.  The three
+// G-sized passes of an iteration (G'DG on the matrix cores, the G'v products, the row products G v) then read half the rows:
+// the functional's weight is d_f + d_{f+mir}, its G'v weight v_f - v_{f+mir}, and G v serves both sides with one product.
 struct BlockQP {
-    int ncp;              // padded row count (multiple of 64)
+    int ncp;              // length of the per-row arrays (multiple of 64): rows padded (mir == 0), or 2 * ngp
     int nz4, zx0, znx;    // rows [0, nz4) act on columns [zx0, zx0 + znx) only (initial-state rows; nz4 = 0: no such block)
-    const double *Grm;    // [ncp][NVP]  scaled G, row-major, zero padded (MFMA operands, G'v passes)
-    const double *Gcm;    // [NVP][ncp]  the same, column-major (thread-per-row products)
-    const double *GHrm;   // [ncp][NVP]  G * Hs^-1, row-major (refinement: S = G_W Hs^-1 G_W')
+    int mir;              // 0, or ngp: offset of a functional's lower side in the per-row arrays
+    int ng, ngp;          // rows of G (nc, or nc / 2 functionals) and their padded count (multiple of 64)
+    const double *Grm;    // [ngp][NVP]  scaled G, row-major, zero padded (MFMA operands, G'v passes)
+    const double *Gcm;    // [NVP][ngp]  the same, column-major (thread-per-row products)
+    const double *Gw;     // [ncp][NVP]  G by constraint row (row f + mir = -row f): the refinement gathers its working rows here; mir == 0: Grm
+    const double *GHrm;   // [ncp][NVP]  G * Hs^-1 by constraint row, row-major (refinement: S = G_W Hs^-1 G_W')
     const double *g0;     // [ncp]       right-hand side offsets (padding rows: 1)
     const double *Es;     // [ncp][nx]   right-hand side dependence on x_k
-    const int32_t *ncols; // [ncp]       columns a row reaches (its zeros beyond are skipped); rows >= nz4 are ordered by it
-    int row_start[9];     // row_start[t]: first row that reaches the 16-column tile t (row_start[0] = nz4; nc if none)
+    const int32_t *ncols; // [ngp]       columns a row of G reaches (its zeros beyond are skipped); rows >= nz4 are ordered by it
+    int row_start[9];     // row_start[t]: first row of G that reaches the 16-column tile t (row_start[0] = nz4; ng if none)
 };
 
 // What solve_block_kernel reads of the model: one record in device memory per variant (written once by tmpc_create), handed

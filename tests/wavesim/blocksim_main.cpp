@@ -31,7 +31,8 @@ int main(int argc, char **argv) {
                              reinterpret_cast<const void **>(&d.Dv), reinterpret_cast<const void **>(&d.Tzs), reinterpret_cast<const void **>(&d.Txf),
                              reinterpret_cast<const void **>(&d.Mth), reinterpret_cast<const void **>(&d.A), reinterpret_cast<const void **>(&d.B),
                              reinterpret_cast<const void **>(&bq.Grm), reinterpret_cast<const void **>(&bq.Gcm), reinterpret_cast<const void **>(&bq.GHrm),
-                             reinterpret_cast<const void **>(&bq.g0), reinterpret_cast<const void **>(&bq.Es), reinterpret_cast<const void **>(&bq.ncols)};
+                             reinterpret_cast<const void **>(&bq.g0), reinterpret_cast<const void **>(&bq.Es), reinterpret_cast<const void **>(&bq.ncols),
+                             reinterpret_cast<const void **>(&bq.Gw)};
     std::vector<std::unique_ptr<char[]>> keep;
     for (const void **fp : fields) {
         uint64_t n;
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
         *fp = keep.back().get();
     }
     std::fclose(f);
+    if (bq.Gw == nullptr) bq.Gw = bq.Grm;          // a row of G per constraint row (BlockQP::mir == 0)
     d.dbg = nullptr; d.save = nullptr; d.ticks = nullptr;
     d.Gt = d.Hct = d.Psi = d.g0p = d.Esp = nullptr; d.vmask = nullptr; d.row_of = nullptr;
 
