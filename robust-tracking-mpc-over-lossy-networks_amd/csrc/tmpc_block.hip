@@ -966,9 +966,21 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     bool spd = false;
                     for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
                         __syncthreads();
-                        for (int idx = tid; idx < NVP * NVP; idx += BT) {
-                            const int i = idx / NVP, j = idx - i * NVP;
-                            big[i * LDM + j] = qp.Hs[idx] + (i == j ? shift : 0.0);
+                        {
+                            // (eight loads in flight: one at a time the copy was 32 dependent L2 round trips per thread)
+                            const double *__restrict__ Hsg = qp.Hs;
+                            constexpr int PER = NVP * NVP / BT, CH = PER >= 8 ? 8 : PER;
+                            static_assert(NVP * NVP % BT == 0 && PER % CH == 0, "Hs copy: whole trips");
+                            for (int c8 = 0; c8 < PER; c8 += CH) {
+                                double hv[CH];
+#pragma unroll
+                                for (int u = 0; u < CH; ++u) hv[u] = Hsg[tid + (c8 + u) * BT];
+#pragma unroll
+                                for (int u = 0; u < CH; ++u) {
+                                    const int idx = tid + (c8 + u) * BT, i = idx / NVP, j = idx - i * NVP;
+                                    big[i * LDM + j] = hv[u] + (i == j ? shift : 0.0);
+                                }
+                            }
                         }
                         __syncthreads();
                         BSTAMP(3);
