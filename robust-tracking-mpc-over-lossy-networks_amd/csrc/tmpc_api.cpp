@@ -468,7 +468,7 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
             if (rcw) return rcw;
             // the workspace slices are sized for the largest variant; a slice is addressed with this variant's ncp
             HIP_TRY(h, tmpc::launch_block(v.db, v.bq, v.bargs, v.tiles, h->blk_ws, h->blk_blocks, k, B, x_k, ref, variant, u_nom, x_nom0,
-                                          xu_ss, x_nom, status, iters, h->stream));
+                                          xu_ss, x_nom, status, iters, &h->wc, h->stream));
             continue;
         }
         if (tmpc::parks_in_lds(v.shape)) {

@@ -56,6 +56,7 @@ struct BlockLaunch {
     const uint8_t *variant;
     double *u_nom, *x_nom0, *xu_ss, *x_nom;
     int32_t *status, *iters;
+    unsigned long long *next_item;      // work counter of this launch (zero at its start): instances beyond the grid's first round
 };
 
 #ifdef TMPC_HOST_SIM
@@ -831,7 +832,25 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
 #define rr_ WSP(WS_RR)
 #define inW_ (reinterpret_cast<int *>(WSP(WS_INW)))
 
-    for (int64_t b = blockIdx.x; b < lp->B; b += gridDim.x) {
+    // Work distribution: the first instance of a workgroup is its index in the grid, the later ones are drawn from the launch's
+    // counter.  An instance costs anything between the set-up alone (the unconstrained minimiser is feasible: a quarter of
+    // config 5) and a dozen iterations; with the static stride of round 2 the launch ended with the unluckiest of 256 sums of 64
+    // such times, a quarter above their mean.
+    long long *const draw = reinterpret_cast<long long *>(red + 44);
+    bool first_item = true;
+    for (;;) {
+        int64_t b;
+        if (first_item) {
+            b = blockIdx.x;
+            first_item = false;
+        } else {
+            ARGS_REFRESH();
+            __syncthreads();            // (every thread has read the previous draw)
+            if (tid == 0) draw[0] = static_cast<long long>(gridDim.x) + static_cast<long long>(atomicAdd(lp->next_item, 1ull));
+            __syncthreads();
+            b = draw[0];
+        }
+        if (b >= lp->B) break;
         { const uint8_t *const variant = lp->variant; const int variant_id = lp->variant_id;
           if (variant != nullptr && variant[b] != variant_id) continue;
         if (variant == nullptr && variant_id != 0) continue; }
@@ -1302,15 +1321,16 @@ unsigned long sim_rendezvous_total = 0;
 template <int T>
 hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, double *ws, int ws_blocks, int variant_id, int64_t B,
                           const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
-                          double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
+                          double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, WorkCounter *wc, hipStream_t stream) {
     constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
     static_assert(lds <= 160 * 1024, "block shape does not fit the 160 KiB LDS of a CU");
-    (void)ws_blocks; (void)stream; (void)dargs;
+    (void)ws_blocks; (void)stream; (void)dargs; (void)wc;
+    unsigned long long counter = 0, *next_item = &counter;
     const BlockArgs host_args{qp, bq};
     sim::Dim3 bi, gd;
     bi.x = bi.y = bi.z = 0;
     sim_rendezvous_total += sim::run_block(BShape<T>::BT, lds, bi, gd, [&]() {
-        solve_block_kernel<T>(BlockLaunch{&host_args, qp.ticks, qp.dbg, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters});
+        solve_block_kernel<T>(BlockLaunch{&host_args, qp.ticks, qp.dbg, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, next_item});
     });
     return hipSuccess;
 }
@@ -1320,7 +1340,7 @@ int block_occupancy_t() { return 1; }
 template <int T>
 hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, double *ws, int ws_blocks, int variant_id, int64_t B,
                           const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
-                          double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
+                          double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, WorkCounter *wc, hipStream_t stream) {
     constexpr size_t lds = sizeof(double) * BShape<T>::TOTAL;
     static_assert(lds <= 160 * 1024, "block shape does not fit the 160 KiB LDS of a CU");
     static std::atomic<bool> attr_set[64] = {};       // (the size is a compile-time constant here: setting it twice is harmless)
@@ -1332,12 +1352,20 @@ hipError_t launch_block_t(const DeviceQP &qp, const BlockQP &bq, const BlockArgs
         if (e != hipSuccess) return e;
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id].store(true, std::memory_order_release);
     }
-    if (dargs == nullptr) return hipErrorInvalidValue;
+    if (dargs == nullptr || wc == nullptr || wc->ring == nullptr) return hipErrorInvalidValue;
     (void)bq;
+    // a fresh (zero) word of the counter ring per launch; the ring is cleared in one piece when it has gone round (tmpc_device.hpp)
+    if (wc->pos >= wc->size) {
+        hipError_t e0 = hipMemsetAsync(wc->ring, 0, sizeof(unsigned long long) * wc->size, stream);
+        if (e0 != hipSuccess) return e0;
+        wc->pos = 0;
+    }
+    unsigned long long *const next_item = wc->ring + wc->pos;
+    ++wc->pos;
     int64_t blocks = B < ws_blocks ? B : ws_blocks;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL((solve_block_kernel<T>), dim3(static_cast<unsigned>(blocks)), dim3(BShape<T>::BT), lds, stream,
-                       BlockLaunch{dargs, qp.ticks, qp.dbg, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters});
+                       BlockLaunch{dargs, qp.ticks, qp.dbg, ws, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, next_item});
     return hipGetLastError();
 }
 
@@ -1390,12 +1418,12 @@ int block_occupancy(int tiles) {
 
 hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
-                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream) {
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, WorkCounter *wc, hipStream_t stream) {
     switch (tiles) {
-        case 1: return launch_block_t<1>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
-        case 2: return launch_block_t<2>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
-        case 4: return launch_block_t<4>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
-        case 8: return launch_block_t<8>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, stream);
+        case 1: return launch_block_t<1>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, wc, stream);
+        case 2: return launch_block_t<2>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, wc, stream);
+        case 4: return launch_block_t<4>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, wc, stream);
+        case 8: return launch_block_t<8>(qp, bq, dargs, ws, ws_blocks, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, wc, stream);
     }
     return hipErrorInvalidValue;
 }

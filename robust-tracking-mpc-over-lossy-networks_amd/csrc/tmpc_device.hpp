@@ -99,7 +99,7 @@ size_t lds_bytes(const KernelShape &shape, int grows);      // grows = 4 * nks r
 const char *kernel_name(const KernelShape &shape);
 bool parks_in_lds(const KernelShape &shape);               // the hand-over iterate stays in LDS: no DeviceQP::save slot needed
 
-// Work counters of the wave kernel's persistent grid: every launch draws its instances from a fresh, zeroed device word of
+// Work counters of the persistent grids (wave kernel and block kernel): every launch draws its instances from a fresh, zeroed device word of
 // a ring that is cleared in one piece when it has gone round -- no reset and no extra stream operation per launch.
 // Launches that share a ring must be ordered on one stream.
 struct WorkCounter {
@@ -121,7 +121,7 @@ int block_occupancy(int tiles);
 // dargs: the device copy of {qp, bq} (unused on the host execution model of tests/wavesim, which reads qp / bq directly)
 hipError_t launch_block(const DeviceQP &qp, const BlockQP &bq, const BlockArgs *dargs, int tiles, double *ws, int ws_blocks, int variant_id, int64_t B,
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
-                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, hipStream_t stream);
+                        double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, WorkCounter *wc, hipStream_t stream);
 
 // Device-resident closed loop (tmpc_mc.hip)
 struct McModel {

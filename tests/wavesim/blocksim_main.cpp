@@ -63,7 +63,7 @@ int main(int argc, char **argv) {
     // the per-workgroup workspace: uninitialised on purpose
     std::unique_ptr<double[]> ws(new double[static_cast<size_t>(tmpc::block_workspace_rows()) * bq.ncp]);
     const hipError_t e = tmpc::launch_block(d, bq, nullptr, hd[0], ws.get(), 1, 0, B, xk.data(), ref.data(), nullptr, u.get(), x0.get(), ss.get(), nullptr,
-                                           st.get(), it.get(), nullptr);
+                                           st.get(), it.get(), nullptr, nullptr);
     need(e == hipSuccess, "launch failed");
     std::fprintf(stderr, "blocksim: tmpc::solve_block_kernel<%d>, %lld instances\n", hd[0], static_cast<long long>(B));
     FILE *o = std::fopen(argv[3], "wb");
