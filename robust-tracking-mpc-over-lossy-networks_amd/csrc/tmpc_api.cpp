@@ -298,7 +298,12 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
         order[k] = k;
     }
     std::stable_sort(order.begin() + nz4, order.end(), [&](int a, int b) { return ext[a] < ext[b]; });
-    std::vector<double> Grm(static_cast<size_t>(ngp) * NVP, 0.0), Gcm(Grm.size(), 0.0), g0(ncp, 1.0), Es(static_cast<size_t>(ncp) * nx, 0.0);
+    // (Grm: the NVP rows of the scaled Hessian, identity on the padding, follow the rows of G -- gt_products adds Hs z in its pass)
+    std::vector<double> Grm(static_cast<size_t>(ngp + NVP) * NVP, 0.0), Gcm(static_cast<size_t>(ngp) * NVP, 0.0), g0(ncp, 1.0),
+        Es(static_cast<size_t>(ncp) * nx, 0.0);
+    for (int i = 0; i < NVP; ++i)
+        for (int j = 0; j < NVP; ++j)
+            Grm[static_cast<size_t>(ngp + i) * NVP + j] = (i < c.nv && j < c.nv) ? c.Hs(i, j) : (i == j ? 1.0 : 0.0);
     std::vector<double> Gw(paired ? static_cast<size_t>(ncp) * NVP : 0, 0.0), GH(static_cast<size_t>(ncp) * NVP, 0.0);
     std::vector<int32_t> ncols(ngp, c.nv);
     for (int t = 0; t <= 8; ++t) v.bq.row_start[t] = ng;

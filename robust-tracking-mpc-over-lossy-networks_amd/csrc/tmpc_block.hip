@@ -224,9 +224,12 @@ __device__ __noinline__ double column_sums(const double *__restrict__ Hm, const 
 }
 
 // out_a = G' va, out_b = G' vb (LDS vectors of NVP entries); va, vb are per-row workspace arrays.
+// zext != nullptr: Hs zext is added to BOTH -- the NVP rows of the (symmetric) scaled Hessian sit behind the rows of G in Grm and
+// ride along in this pass, which streams at the L1 rate, instead of costing a product of their own (four dependent L2 round
+// trips with a handful of loads in flight: 5 % of an instance's time in round 2's form).
 template <int T>
 __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc, const double *va, const double *vb,
-                                            double *parts, double *out_a, double *out_b, int tid, CBlockQP &bq) {
+                                            double *parts, double *out_a, double *out_b, int tid, CBlockQP &bq, const double *zext = nullptr) {
     constexpr int NVP = BShape<T>::NVP, PARTS = BShape<T>::PARTS, BT = BShape<T>::BT, NV2 = NVP / 2;
     typedef double v2d __attribute__((ext_vector_type(2)));
     // thread = (column pair, row part): 16-byte loads, a wave covers whole rows of G; the operands come from L2 or beyond
@@ -275,6 +278,27 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
     for (; r < nc; r += PARTS) {
         const v2d g0 = (r >= rs) ? G2[static_cast<size_t>(r) * NV2] : zero2;
         a0 += g0 * wt(va, r); b0 += g0 * wt(vb, r);
+    }
+    if (zext != nullptr) {
+        const size_t hs0 = static_cast<size_t>(bq.ngp);          // first row of Hs in Grm
+        constexpr int HR = (NVP + PARTS - 1) / PARTS, CH = HR > 8 ? 8 : HR;       // rows of Hs per thread, rows in flight
+        static_assert(HR % CH == 0, "whole batches");
+        v2d hs = {0.0, 0.0};
+#pragma unroll
+        for (int u0 = 0; u0 < HR; u0 += CH) {
+            v2d hg[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = part + (u0 + u) * PARTS;
+                hg[u] = j < NVP ? G2[(hs0 + j) * NV2] : zero2;
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = part + (u0 + u) * PARTS;
+                hs += hg[u] * (j < NVP ? zext[j] : 0.0);
+            }
+        }
+        a0 += hs; b0 += hs;
     }
     __syncthreads();                       // previous readers of `parts` are done
     a0 += a1; b0 += b1;
@@ -931,11 +955,13 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                 for (; it < qp.max_iter; ++it) {
                     it_done = it;
                     // ---- P1: residuals and scalings per row
-                    double gap = 0.0, rpn = 0.0, lmax = 0.0;
+                    double gap = 0.0, rpn = 0.0, lmax = 0.0, gzl = 0.0;
                     for (int r = tid; r < ncp; r += BT) {
                         const bool valid = valid_row(r);
                         const double sv = s_[r], lv = lam_[r];
-                        const double rp = gz_[r] + sv - h_[r];
+                        const double gzr = gz_[r];
+                        const double rp = gzr + sv - h_[r];
+                        gzl = fma(gzr, lv, gzl);
                         const double rs = valid ? fast_rcp(sv) : 0.0;
                         const double d = lv * rs;
                         rp_[r] = rp;
@@ -946,23 +972,21 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         lmax = fmax(lmax, lv);
                     }
                     block_reduce3<SH::BW, OpSum, OpMax, OpMax>(gap, rpn, lmax, red, wave, lane);
+                    gzl = block_reduce1<SH::BW, OpSum>(gzl, red, wave, lane);          // (G z)' lam
                     const double mu = gap / ncd;
                     BSTAMP(1);
-                    // ---- P2: cost gradient, G'lam, G'(d.rp)
-                    {
-                        const double v = column_sums<T>(qp.Hs, zv, nullptr, nullptr, nullptr, 0, parts, tid);
-                        if (tid < NVP) cgv[tid] = qv[tid] + v;
-                    }
-                    gt_products<T>(Grm, ng, lam_, v1_, parts, glv, tv, tid, bq);
-                    double rdn = 0.0, obj = 0.0, gln = 0.0;
+                    // ---- P2: dual residual and predictor right-hand side.  Hs z rides along in the pass over G (gt_products):
+                    // glv = Hs z + G'lam, tv = Hs z + G'(d.rp); the objective takes z'Hs z = z'glv - (G z)'lam
+                    gt_products<T>(Grm, ng, lam_, v1_, parts, glv, tv, tid, bq, zv);
+                    double rdn = 0.0, obj = 0.0, dum2 = 0.0;
                     if (tid < NVP) {
-                        const double cgj = cgv[tid], qj = qv[tid];
-                        rdn = fabs(cgj + glv[tid]);
-                        obj = zv[tid] * (0.5 * (cgj - qj) + qj);
-                        gln = fabs(glv[tid]);
-                        rhsv[tid] = -cgj - tv[tid];
+                        const double qj = qv[tid], aj = glv[tid];
+                        rdn = fabs(qj + aj);
+                        obj = zv[tid] * (0.5 * aj + qj);
+                        rhsv[tid] = -qj - tv[tid];
                     }
-                    block_reduce3<SH::BW, OpMax, OpSum, OpMax>(rdn, obj, gln, red, wave, lane);
+                    block_reduce3<SH::BW, OpMax, OpSum, OpMax>(rdn, obj, dum2, red, wave, lane);
+                    obj -= 0.5 * gzl;
                     BSTAMP(2);
                     if (!(mu == mu) || !(rdn == rdn)) { st = TMPC_STATUS_NUMERICAL; break; }
                     const double objs = fmax(fabs(obj), 1.0);
@@ -978,6 +1002,11 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                         double hl = 0.0;
                         for (int r = tid; r < ncp; r += BT) hl += h_[r] * lam_[r];          // (padding rows: lambda = 0)
                         hl = block_reduce1<SH::BW, OpSum>(hl, red, wave, lane);
+                        // |G'lam| on its own (rare path: a pass without the rows of Hs; tv is rebuilt by the next iteration's P2
+                        // and not read before, rhsv is complete)
+                        gt_products<T>(Grm, ng, lam_, v1_, parts, glv, tv, tid, bq);
+                        double gln = (tid < NVP) ? fabs(glv[tid]) : 0.0;
+                        gln = block_reduce1<SH::BW, OpMax>(gln, red, wave, lane);
                         if (hl < 0.0 && gln <= 1e-6 * lmax) { st = TMPC_STATUS_INFEASIBLE; break; }
                     }
                     // ---- P3 + P4: M = Hs + G'DG (MFMA), Cholesky, predictor solve

@@ -69,7 +69,7 @@ struct BlockQP {
     int nz4, zx0, znx;    // rows [0, nz4) act on columns [zx0, zx0 + znx) only (initial-state rows; nz4 = 0: no such block)
     int mir;              // 0, or ngp: offset of a functional's lower side in the per-row arrays
     int ng, ngp;          // rows of G (nc, or nc / 2 functionals) and their padded count (multiple of 64)
-    const double *Grm;    // [ngp][NVP]  scaled G, row-major, zero padded (MFMA operands, G'v passes)
+    const double *Grm;    // [ngp + NVP][NVP]  scaled G, row-major, zero padded (MFMA operands, G'v passes), then the rows of Hs (gt_products)
     const double *Gcm;    // [NVP][ngp]  the same, column-major (thread-per-row products)
     const double *Gw;     // [ncp][NVP]  G by constraint row (row f + mir = -row f): the refinement gathers its working rows here; mir == 0: Grm
     const double *GHrm;   // [ncp][NVP]  G * Hs^-1 by constraint row, row-major (refinement: S = G_W Hs^-1 G_W')

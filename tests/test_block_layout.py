@@ -52,7 +52,9 @@ def test_every_constraint_row_sits_on_one_side_of_a_functional(name, N, fixed, h
     NVP, nx = 16 * tiles, mpc._nx
     ncp, mir, ng, ngp = bq["ncp"], bq["mir"], bq["ng"], bq["ngp"]
     assert mir == ngp and ncp == 2 * ngp and 2 * ng == nc and ngp % 64 == 0 and bq["nz4"] == 0         # all rows paired
-    Grm = a["Grm"].reshape(ngp, NVP)
+    Grm = a["Grm"].reshape(ngp + NVP, NVP)
+    assert np.array_equal(Grm[ngp:], a["Hs"].reshape(NVP, NVP))          # the rows of Hs ride along in the G'v pass
+    Grm = Grm[:ngp]
     assert np.array_equal(a["Gcm"].reshape(NVP, ngp), Grm.T)
     Gw, GH = a["Gw"].reshape(ncp, NVP), a["GHrm"].reshape(ncp, NVP)
     assert np.array_equal(Gw[:ngp], Grm) and np.array_equal(Gw[mir:], -Grm) and np.array_equal(GH[mir:], -GH[:ngp])
