@@ -65,6 +65,7 @@ typedef const BlockArgs *ArgsPtr;
 typedef const BlockQP CBlockQP;
 typedef const DeviceQP CDeviceQP;
 #define ARGS_REFRESH() do { } while (0)
+inline double fresh_value(double v) { return v; }
 #else
 typedef const __attribute__((address_space(4))) BlockLaunch *LaunchPtr;
 typedef const __attribute__((address_space(4))) BlockArgs *ArgsPtr;
@@ -73,6 +74,7 @@ typedef const __attribute__((address_space(4))) DeviceQP CDeviceQP;
 // (through a vector register and v_readfirstlane: the compiler takes phase boundaries behind LDS-derived conditions for divergent
 // control flow and would not keep an "s"-constrained value in scalar registers there)
 __device__ __forceinline__ int fresh_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ double fresh_value(double v) { asm volatile("" : "+v"(v)); return v; }
 template <class P>
 __device__ __forceinline__ P fresh_uniform(P p) {
     unsigned lo = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)), hi = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32);
@@ -189,19 +191,38 @@ __device__ __forceinline__ void row_dot2(const double *__restrict__ Gcm, int ncp
 template <int T>
 __device__ __noinline__ double column_sums(const double *__restrict__ Hm, const double *v, const double *__restrict__ R, const int *idx,
                                               const double *w, int m, double *parts, int tid) {
-    constexpr int NVP = BShape<T>::NVP, P = BShape<T>::BT / NVP;
+    constexpr int NVP = BShape<T>::NVP, BT = BShape<T>::BT, P = BT / NVP;
     const int c = tid % NVP, part = tid / NVP;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // Hm: thread (column pair, row part), 16-byte loads, eight of the thread's rows in flight (the matrix comes from L2: the
+    // product is two round trips for T = 8 instead of four with half the requests)
+    constexpr int NV2 = NVP / 2, PH = BT / NV2, RPT = (NVP + PH - 1) / PH;      // row parts, rows per thread
+    typedef double v2d __attribute__((ext_vector_type(2)));
     if (Hm != nullptr) {
-        if constexpr (NVP / P >= 4) {
-#pragma unroll 2
-            for (int j = part; j < NVP; j += 4 * P) {
-                const double h0 = Hm[j * NVP + c], h1 = Hm[(j + P) * NVP + c], h2 = Hm[(j + 2 * P) * NVP + c], h3 = Hm[(j + 3 * P) * NVP + c];
-                a0 = fma(h0, v[j], a0); a1 = fma(h1, v[j + P], a1); a2 = fma(h2, v[j + 2 * P], a2); a3 = fma(h3, v[j + 3 * P], a3);
+        const int c2 = tid % NV2, ph = tid / NV2;
+        const v2d *__restrict__ H2 = reinterpret_cast<const v2d *>(Hm) + c2;
+        constexpr int CH = RPT > 8 ? 8 : RPT;          // rows in flight per batch (T = 8: two batches of eight)
+        static_assert(RPT % CH == 0, "whole batches");
+        v2d s0 = {0.0, 0.0}, s1 = {0.0, 0.0};
+#pragma unroll
+        for (int u0 = 0; u0 < RPT; u0 += CH) {
+            v2d hv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = ph + (u0 + u) * PH;
+                hv[u] = j < NVP ? H2[static_cast<size_t>(j) * NV2] : v2d{0.0, 0.0};
             }
-        } else {
-            for (int j = part; j < NVP; j += P) a0 = fma(Hm[j * NVP + c], v[j], a0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int j = ph + (u0 + u) * PH;
+                const double vj = j < NVP ? v[j] : 0.0;
+                if (u & 1) s1 += hv[u] * vj; else s0 += hv[u] * vj;
+            }
         }
+        s0 += s1;
+        __syncthreads();                   // previous readers of `parts` are done
+        parts[P * NVP + ph * NVP + 2 * c2] = s0.x;
+        parts[P * NVP + ph * NVP + 2 * c2 + 1] = s0.y;
     }
     if (R != nullptr) {
         int k = part;
@@ -212,13 +233,17 @@ __device__ __noinline__ double column_sums(const double *__restrict__ Hm, const 
         }
         for (; k < m; k += P) a0 = fma(R[static_cast<size_t>(idx[k]) * NVP + c], w[k], a0);
     }
-    __syncthreads();                       // previous readers of `parts` are done
+    if (Hm == nullptr) __syncthreads();    // previous readers of `parts` are done
     parts[part * NVP + c] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     double sum = 0.0;
     if (tid < NVP) {
 #pragma unroll
         for (int p2 = 0; p2 < P; ++p2) sum += parts[p2 * NVP + tid];
+        if (Hm != nullptr) {
+#pragma unroll
+            for (int p2 = 0; p2 < PH; ++p2) sum += parts[P * NVP + p2 * NVP + tid];
+        }
     }
     return sum;
 }
@@ -1265,7 +1290,9 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                 }
                 BSTAMP(10);
                 if (ok) { st = TMPC_STATUS_OPTIMAL; break; }
-                if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * qn) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
+                // (the product is formed here, from an opaque copy: hoisted to the top of the instance it was a register that lived -- and at
+                // T = 8 was spilled -- through the whole solve for the sake of this rare exit)
+                if (try_tol <= 1e-12) { st = (rdn_last <= 1e-9 * fresh_value(qn)) ? TMPC_STATUS_OPTIMAL : TMPC_STATUS_MAX_ITER; break; }
                 try_tol *= 1e-2;
             }
             // (iteration cap: the last iterate goes out under TMPC_STATUS_MAX_ITER, see tmpc_kernels.hip; INFEASIBLE needs the
