@@ -170,6 +170,9 @@ int tmpc_solve_batch_device(tmpc_handle *h, int64_t B,
  * FP64 matrix cores).  TMPC_PATH_WAVE / TMPC_PATH_BLOCK force one of them (TMPC_E_UNSUPPORTED if
  * it cannot take the problem).  Results agree to the refinement's accuracy either way
  * (tests/test_hip_parity.py).  tmpc_get_kernel_path reports the path a variant currently takes.
+ * Environment (developer knob, read by tmpc_create): TMPC_BLOCK_PAIRS=0 makes the workgroup-per-QP
+ * kernel keep one row of G per constraint row instead of one per pair of mirrored rows
+ * (DESIGN.md section 4); the answers agree (tests/test_block_layout.py).
  */
 #define TMPC_PATH_AUTO  0
 #define TMPC_PATH_WAVE  1
