@@ -15,6 +15,7 @@ pl.set_lp_backend("hip")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 ncase = int(sys.argv[2]) if len(sys.argv) > 2 else 12
 long_horizon = len(sys.argv) > 3 and sys.argv[3] == "long"       # aim at the largest wave-kernel shape (24 variables)
+force_block = len(sys.argv) > 3 and sys.argv[3] == "block"       # every case through the workgroup-per-QP kernel
 worst = 0.0
 for case in range(ncase):
     n = int(rng.integers(2, 9)); m = int(rng.integers(1, 3)); N = int(rng.integers(3, 27 if m == 1 else 16))
@@ -44,6 +45,8 @@ for case in range(ncase):
     var = rng.integers(0, 2, Bsz).astype(np.uint8) if ext else None
     orc = Oracle(mpc._problem_dict())
     ref = orc.solve(X, Rf, var) if ext else orc.solve(X, Rf)
+    if force_block:
+        mpc.set_kernel_path("block")
     out = mpc._solve(X, Rf, var)
     same = np.array_equal(out["status"], ref["status"])
     ok = (ref["status"] == 0) & (out["status"] == 0)
