@@ -1160,13 +1160,15 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     const size_t b = static_cast<size_t>(B), dd = static_cast<size_t>(d);
     const size_t nws = static_cast<size_t>(nblocks) * wpb * tmpc::lp_workspace_arrays() * nrp;
     const size_t need = lp_round(Ht.size() * 8) + 2 * lp_round(static_cast<size_t>(nrp) * 8) + 2 * lp_round(b * dd * 8) + lp_round(nws * 8) +
-                        lp_round(b * 8) + 3 * lp_round(b * 4) + 256;
+                        lp_round(b * 8) + 3 * lp_round(b * 4) + 512;
     LpArena &ar = g_lp_arena;
     LP_TRY(ar.reserve(device, need));
     double *dHt = ar.take<double>(Ht.size()), *dh = ar.take<double>(nrp), *drs = ar.take<double>(nrp);
     double *dC = ar.take<double>(b * dd), *dws = ar.take<double>(nws), *dval = ar.take<double>(b);
     double *dx = x ? ar.take<double>(b * dd) : nullptr;
     int32_t *dst = ar.take<int32_t>(b), *dit = ar.take<int32_t>(b), *drel = relax ? ar.take<int32_t>(b) : nullptr;
+    unsigned long long *dnext = ar.take<unsigned long long>(1);
+    LP_TRY(hipMemset(dnext, 0, sizeof(unsigned long long)));
     if (relax) LP_TRY(hipMemcpy(drel, relax, b * sizeof(int32_t), hipMemcpyHostToDevice));
     LP_TRY(hipMemcpy(dHt, Ht.data(), Ht.size() * sizeof(double), hipMemcpyHostToDevice));
     LP_TRY(hipMemcpy(dh, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice));
@@ -1176,6 +1178,7 @@ int tmpc_lp_batch(int device, int32_t d, int32_t nr, const double *H, const doub
     lp.d = d; lp.nr = nr; lp.nrp = nrp; lp.max_iter = LP_MAX_ITER;
     lp.tol = LP_TOL; lp.relax_by = relax_by; lp.hm = hm;
     lp.Ht = dHt; lp.h = dh; lp.rscale = drs;
+    lp.next_item = dnext;
     LP_TRY(tmpc::launch_lp(lp, B, nblocks, dC, drel, dws, dval, dx, dst, dit, nullptr));
     LP_TRY(hipDeviceSynchronize());
     LP_TRY(hipMemcpy(val, dval, b * sizeof(double), hipMemcpyDeviceToHost));

@@ -171,6 +171,7 @@ struct LpDevice {
     const double *Ht;     // [DP][nrp]  H transposed, zero padded (DP = lp_padded_dim(d))
     const double *h;      // [nrp]      padding rows: 1
     const double *rscale; // [nrp]      1 / (|H_r| hm): caller units of h -> kernel units
+    unsigned long long *next_item;   // work counter of the launch, zero at its start (LPs beyond every wave's first)
 };
 int lp_padded_dim(int d);
 int lp_waves_per_block();

@@ -313,7 +313,21 @@ __global__ __launch_bounds__(WAVE *LP_WPB, 1) void lp_kernel(LpDevice p, int64_t
     double *s_ = ws + static_cast<size_t>(slot) * LP_ARR * nrp;
     double *lam_ = s_ + nrp, *gz_ = lam_ + nrp, *w_ = gz_ + nrp, *ds_ = w_ + nrp, *dl_ = ds_ + nrp;
 
-    for (int64_t b = slot; b < B; b += nslots) {
+    // Work distribution: the first LP of a wave is its slot, the later ones are drawn from the launch's counter (LPs of one batch
+    // differ by a factor of three in their iteration counts, and the hard ones -- hand-overs that fail, ascent steps -- by much more)
+    bool first_item = true;
+    for (;;) {
+        int64_t b;
+        if (first_item) {
+            b = slot;
+            first_item = false;
+        } else {
+            unsigned long long drawn = 0;
+            if (lane == 0) drawn = atomicAdd(p.next_item, 1ull);
+            b = nslots + static_cast<int64_t>((static_cast<unsigned long long>(static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(drawn >> 32)))) << 32) |
+                                              static_cast<unsigned>(__builtin_amdgcn_readfirstlane(static_cast<int>(drawn & 0xffffffffull))));
+        }
+        if (b >= B) break;
         // ---- objective
         const double cl = lane < d ? C[b * d + lane] : 0.0;
         const double cn = sqrt(wave_reduce<OpSum>(cl * cl));
@@ -838,7 +852,10 @@ hipError_t launch_lp_ds(const LpDevice &p, int64_t B, int nblocks, const double 
     (void)nblocks; (void)stream;
     sim::Dim3 bi, gd;
     bi.x = bi.y = bi.z = 0;
-    sim::run_block(WAVE * LP_WPB, lds, bi, gd, [&]() { lp_kernel<D, STAGED>(p, B, C, relax, ws, val, xout, status, iters); });
+    unsigned long long counter = 0;
+    LpDevice ps = p;
+    ps.next_item = &counter;
+    sim::run_block(WAVE * LP_WPB, lds, bi, gd, [&]() { lp_kernel<D, STAGED>(ps, B, C, relax, ws, val, xout, status, iters); });
     return hipSuccess;
 #else
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&lp_kernel<D, STAGED>), hipFuncAttributeMaxDynamicSharedMemorySize,
