@@ -4,7 +4,8 @@
 tag=${1:-r02}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rm -rf gpurun_out/prof_$tag* gpurun_out/pmc_${tag}_*      # (the merge back keeps older files of the same name otherwise)
-BENCH="python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-closed-loop --no-extras"
+# (long enough for the card to be past its clock ramp for most of the launches: DESIGN.md "How bench.py times")
+BENCH="python3 bench.py --steps 200 --warmup 60 --no-cpu-baseline --no-closed-loop --no-extras"
 # ---- the bench kernel (BASELINE configs[1])
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- $BENCH > gpurun_out/prof_$tag.json 2> gpurun_out/prof_$tag.err
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d gpurun_out/pmc_${tag}_$name -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-closed-loop --no-extras > gpurun_out/pmc_${tag}_$name.log 2>&1; }
