@@ -301,7 +301,9 @@ def main():
                                  "note": "support LPs over the terminal set, host buffers in and out (set-up stage, DESIGN.md 7a)"}
             ex["config3"] = config3_extra()
             ex["config5"] = config5_extra()
-            # (last of the extras, so that the headline's warm-up steps follow a dense sequence of launches of its own kernel)
+        if not args.no_extras:
+            # (on every rank, and last of the extras: the headline's warm-up steps then follow a dense sequence of launches of its
+            # own kernel for every N, so that the per-N values the scaling efficiency is computed from are measured alike)
             # two handles (two streams) taking turns over the same batches: a launch of 4096 ends with its slowest instance
             # (two instances per resident wave), and the tail of one launch overlaps with the head of the next when it is
             # on another stream -- the throughput a server sees that pipelines its batches.  `value` above stays the
@@ -320,9 +322,14 @@ def main():
             for h_ in hs:
                 _native.synchronize(h_)
             tp = time.perf_counter() - tp
-            ex["pipelined"] = {"value": B * args.steps / tp, "unit": "solves/s", "handles": 2, "steps": args.steps,
+            if use_pg:
+                tpm = torch.tensor([tp], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tpm, op=dist.ReduceOp.MAX)
+                tp = float(tpm.item())
+            ex["pipelined"] = {"value": world * B * args.steps / tp, "unit": "solves/s", "handles": 2, "steps": args.steps,
                                 "ms_per_step": tp / args.steps * 1e3,
-                                "note": "same batches, two handles on their own streams taking turns (tails of successive launches overlap)"}
+                                "note": "same batches, two handles per GPU on their own streams taking turns (tails of successive launches "
+                                        "overlap); whole job, slowest rank"}
         return ex
 
     # torch's own kernels and the collective are loaded / set up here, NOT between the warm-up steps and the timed ones: the first
@@ -332,7 +339,7 @@ def main():
     _native.synchronize(h)
     gather_stats()
     fence()
-    extras_out = extras() if (rank == 0 and world == 1) else {}
+    extras_out = extras()
     torch.cuda.synchronize()
 
     for i in range(args.warmup):
