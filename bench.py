@@ -20,8 +20,14 @@ Metric: QP solves per second (= MPC steps per second), whole job.  The same JSON
   cpu_baseline  the CPU oracle (oracle/tmpc_oracle.c, OpenMP over the batch) timed on this box's host cores on a
                 bounded sample of the same workload;
   extras        closed loop on the device (cold and warm-started), BASELINE configs[2] (N = 20 extended controller,
-                batch 65536, gamma from a real closed loop) and configs[4] (n = 12, m = 4, N = 30, batch 16384), each with
-                its own roofline, and the offline LP stage.
+                batch 65536, gamma from a real closed loop) and configs[4] (n = 12, m = 4, N = 30, batch 16384; plus a HARD
+                leg with an eighth of the states far out), each with its own roofline, and the offline LP stage;
+  single_call   the reference's own timing table (results_linear_system.py:305-315: max / 95 / 90 / 75 % / median / mean of
+                the wall time of one determine_packet call, in ms) for 1000 calls at batch 1 through tmpc_solve_batch, host
+                pointers, copies included -- and for the CPU oracle on one thread;
+  closed_loop_small   the reference's own experiment size (results_linear_system.py:64,147-149: N = 20, 10 loss rates x 20
+                runs x 250 steps) through the device-resident loop, wall seconds;
+  ranks_seen / per_rank_ms   (multi-GPU) an all-reduce of ones and every rank's own timed region and average kernel time.
 Order of a one-GPU run: set-up, one solve + the statistics gather (loads torch's kernels), the extras, THEN the W warm-up steps and
 the K timed steps.  The first torch kernel of a process costs tens of milliseconds of host time; placed between the warm-up steps and
 the timed ones (round 2) it let the card idle, and its clocks need some fifty launches to come back: 4 % on the average kernel
@@ -51,6 +57,15 @@ def flops_per_iteration(nv, nc):
     return nc * nv * nv + nv ** 3 / 3.0 + 8.0 * nc * nv + 4.0 * nv * nv
 
 
+def flops_per_iteration_factored(nv, nd, ncc, kc):
+    """The same count with the low-rank block priced at its rank: the ncc rows kept as Hc * Psi cost kc per
+    row product and kc^2 per row of G'DG (W = Hc' D Hc), plus Psi' W Psi (2 kc nv^2 ... counted as kc^2 nv + kc nv^2) and the
+    four Psi products of an iteration (8 kc nv); the nd general rows and the factorisation as in flops_per_iteration."""
+    dense = nd * nv * nv + 8.0 * nd * nv
+    fact = ncc * kc * kc + 8.0 * ncc * kc + (kc * kc * nv + kc * nv * nv + 8.0 * kc * nv if ncc else 0.0)
+    return dense + fact + nv ** 3 / 3.0 + 4.0 * nv * nv
+
+
 def host_cores():
     """Cores this process may actually use: the smaller of its affinity mask and its cgroup CPU quota."""
     cores = os.cpu_count() or 1
@@ -67,7 +82,14 @@ def host_cores():
     return cores
 
 
-TRAFFIC_PROFILE = os.path.join("profiles", "r03_bench_pmc_summary.txt")
+def timing_table(seconds):
+    """The statistics the reference prints of its per-call computation times (results_linear_system.py:305-315), in ms."""
+    ms = 1e3 * np.asarray(seconds, dtype=np.float64)
+    return {"max_ms": float(ms.max()), "q95_ms": float(np.quantile(ms, 0.95)), "q90_ms": float(np.quantile(ms, 0.9)),
+            "q75_ms": float(np.quantile(ms, 0.75)), "median_ms": float(np.median(ms)), "mean_ms": float(ms.mean())}
+
+
+TRAFFIC_PROFILE = os.path.join("profiles", "r04_bench_pmc_summary.txt")
 
 
 def measured_traffic(kernel_name):
@@ -132,16 +154,25 @@ def roofline_entry(native, h, batch, gamma, avg_ms):
     """FP64 roofline of one call: sum over the instances of iters * F_it(nv, nc) of their variant."""
     it = batch.it.cpu().numpy().astype(np.float64)
     st = batch.st.cpu().numpy()
-    flops, kernels, dims = 0.0, [], []
+    flops, flops_f, kernels, dims = 0.0, 0.0, [], []
     for v in ([0] if gamma is None else sorted(set(gamma.tolist()))):
         nv, nc, _ = native.get_dims(h, int(v))
+        nd, ncc, kc = native.get_factoring(h, int(v))
+        on_wave = "solve_kernel" in native.kernel_name(h, int(v))        # (the block kernel keeps every row dense)
         m = np.ones(len(it), bool) if gamma is None else (gamma == v)
         flops += float(it[m].sum()) * flops_per_iteration(nv, nc)
+        flops_f += float(it[m].sum()) * (flops_per_iteration_factored(nv, nd, ncc, kc) if on_wave else flops_per_iteration(nv, nc))
         kernels.append(native.kernel_name(h, int(v)))
-        dims.append({"variant": int(v), "nv": nv, "nc": nc, "instances": int(m.sum()), "mean_ipm_iters": float(it[m].mean()) if m.any() else 0.0})
+        dims.append({"variant": int(v), "nv": nv, "nc": nc, "dense_rows": nd, "factored_rows": ncc, "factor_rank": kc,
+                     "instances": int(m.sum()), "mean_ipm_iters": float(it[m].mean()) if m.any() else 0.0})
     ach = flops / (avg_ms * 1e-3) / 1e12
+    achf = flops_f / (avg_ms * 1e-3) / 1e12
     return ({"bound": "mfma", "achieved": ach, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_PEAK_TFLOPS,
-             "kernel": " + ".join(kernels), "avg_kernel_ms": avg_ms, "flops_per_launch": flops},
+             "kernel": " + ".join(kernels), "avg_kernel_ms": avg_ms, "flops_per_launch": flops,
+             "roofline_factored": {"achieved": achf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achf / FP64_PEAK_TFLOPS,
+                                   "flops_per_launch": flops_f,
+                                   "note": "the low-rank row block priced at its rank kc instead of as dense nv-wide rows "
+                                           "(flops_per_iteration_factored); `frac` above is SURVEY.md 8(d)'s dense price"}},
             dims, float((st == 0).mean()), float((st == 2).mean()))
 
 
@@ -173,6 +204,11 @@ def main():
     # TMPC_BENCH_BACKEND=gloo is a rehearsal mode for boxes with fewer GPUs than ranks (ranks share the devices, the
     # statistics gather goes through host memory); the driver's runs use nccl (= RCCL), one rank per GPU
     backend = os.environ.get("TMPC_BENCH_BACKEND", "nccl")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if backend == "nccl" and torch.cuda.device_count() < local_world:
+        print(f"bench.py: {local_world} ranks on this node but only {torch.cuda.device_count()} visible GPU(s): RCCL needs one GPU per rank "
+              "(TMPC_BENCH_BACKEND=gloo rehearses more ranks than GPUs, sharing the devices)", file=sys.stderr)
+        sys.exit(3)
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -196,10 +232,10 @@ def main():
         p3 = np.random.default_rng(3000 + rank).permutation(len(X3))
         X3, R3, G3 = X3[p3], R3[p3], G3[p3]
         b3 = DeviceBatch(torch, dev, X3, R3, G3, 20, 1)
-        dt, ms = timed_solves(_native, torch, mpc3._handle, b3, 10, 2)
+        dt, ms = timed_solves(_native, torch, mpc3._handle, b3, 20, 2)
         roof, dims, opt, inf = roofline_entry(_native, mpc3._handle, b3, G3, ms)
-        return {"value": len(X3) * 10 / dt, "unit": "solves/s", "batch": len(X3), "distinct_states": len(X3) // reps, "steps": 10,
-                "ms_per_step": dt / 10 * 1e3, "gamma1_fraction": float(G3.mean()), "optimal_fraction": opt, "infeasible_fraction": inf,
+        return {"value": len(X3) * 20 / dt, "unit": "solves/s", "batch": len(X3), "distinct_states": len(X3) // reps, "steps": 20,
+                "ms_per_step": dt / 20 * 1e3, "gamma1_fraction": float(G3.mean()), "optimal_fraction": opt, "infeasible_fraction": inf,
                 "variants": dims, "roofline": roof,
                 "note": "cartpole N=20, ExtendedTubeTrackingMPC (results_linear_system_with_extendedMPC.py), (x_hat, ref, gamma) from "
                         "512 extended closed loops x 32 steps at p_loss 0.3, tiled to the batch; both problems in one call"}
@@ -213,11 +249,23 @@ def main():
         R5 = np.zeros((B5, 12))
         R5[:, 0] = rng.uniform(-2, 2, B5)
         b5 = DeviceBatch(torch, dev, X5, R5, None, 30, 4)
-        dt, ms = timed_solves(_native, torch, mpc5._handle, b5, 3, 1)
+        K5 = 10
+        dt, ms = timed_solves(_native, torch, mpc5._handle, b5, K5, 1)
         roof, dims, opt, inf = roofline_entry(_native, mpc5._handle, b5, None, ms)
-        return {"value": B5 * 3 / dt, "unit": "solves/s", "batch": B5, "steps": 3, "ms_per_step": dt / 3 * 1e3,
+        out5 = {"value": B5 * K5 / dt, "unit": "solves/s", "batch": B5, "steps": K5, "ms_per_step": dt / K5 * 1e3,
                 "optimal_fraction": opt, "infeasible_fraction": inf, "variants": dims, "roofline": roof,
                 "note": "random stable (A, B), n=12, m=4, N=30, Darup sets, x_k uniform in 0.5 Xc (SURVEY.md 8d)"}
+        # the hard end of the same configuration: an eighth of the states scaled by 1.9 (near the boundary of Xc: many active
+        # rows, some infeasible) -- the mix of tests/test_full_size.py::test_config5_at_16384
+        X5h = X5.copy()
+        X5h[: B5 // 8] *= 1.9
+        b5h = DeviceBatch(torch, dev, X5h, R5, None, 30, 4)
+        dth, msh = timed_solves(_native, torch, mpc5._handle, b5h, K5, 1)
+        roofh, dimsh, opth, infh = roofline_entry(_native, mpc5._handle, b5h, None, msh)
+        out5["hard"] = {"value": B5 * K5 / dth, "unit": "solves/s", "batch": B5, "steps": K5, "ms_per_step": dth / K5 * 1e3,
+                        "optimal_fraction": opth, "infeasible_fraction": infh, "mean_ipm_iters": dimsh[0]["mean_ipm_iters"],
+                        "roofline": roofh, "note": "the same batch with X[:B//8] *= 1.9"}
+        return out5
 
     if args.only:
         out = {"config3": config3_extra, "config5": config5_extra}[args.only]()
@@ -289,6 +337,40 @@ def main():
                                   "note": "end to end incl. upload of the realisations and download of the statistics; warm = every "
                                           "solve first tries the working set of the trajectory's previous step in the exact refinement"}
         if world == 1 and not args.no_extras:
+            # The reference's own performance self-description (results_linear_system.py:305-315): wall time of ONE
+            # determine_packet call, max / quantiles / median / mean in ms.  Here: 1000 calls at batch 1 through tmpc_solve_batch
+            # (host pointers in and out, copies and the synchronisation included), states drawn from the bench batch.
+            ii = np.random.default_rng(11).integers(0, B, 1000)
+            for k in range(20):
+                mpc.determine_packet(X[ii[k]], R[ii[k]], 0)
+            mpc.reset_computational_times()
+            for k in ii:
+                mpc.determine_packet(X[k], R[k], 0)
+            ex["single_call"] = {"device": timing_table(mpc.get_computational_times()), "calls": len(ii), "batch": 1,
+                                 "note": "TubeTrackingMPC.determine_packet (TubeTrackingMPC.py:196-209) -> tmpc_solve_batch, one QP per "
+                                         "call, host buffers, copies included; statistics of results_linear_system.py:305-315 "
+                                         "(the reference's histogram spans 2.5-20 ms)"}
+            mpc.reset_computational_times()
+            # the reference's experiment at its own size (results_linear_system.py:64, 147-149: N = 20, 10 loss rates x 20 runs x
+            # 250 steps), device-resident loop, realisations drawn on the host as the reference does: 200 trajectories are
+            # 200 of the card's 2048 resident waves, so this is a launch-latency figure (two launches per step), not throughput
+            mpc20, w20 = workloads.make_controller("cartpole", 20, True, device=dev_index)
+            pl20 = np.repeat(np.arange(10) / 10.0, 20)
+            th20, ga20, wd20 = montecarlo.draw_realisations(len(pl20), 250, w20["w_bound"], seed=7)
+            ref20 = 0.5 * np.ones(250)
+            mpc20.run_closed_loop(pl20[:8], ref20[:20], th20[:8, :20], ga20[:8, :20], wd20[:8, :20])          # warm-up
+            small = {}
+            for warm in (False, True):
+                ts = time.perf_counter()
+                cl = mpc20.run_closed_loop(pl20, ref20, th20, ga20, wd20, warm_start=warm)
+                ts = time.perf_counter() - ts
+                small["warm" if warm else "cold"] = {"wall_s": ts, "ms_per_step": ts / 250 * 1e3, "MPC_steps_per_s": len(pl20) * 250 / ts,
+                                                     "tube_violations": int(cl["tube_violations"].sum()),
+                                                     "non_optimal_solves": int(cl["not_optimal"].sum())}
+            ex["closed_loop_small"] = {"trajectories": len(pl20), "steps": 250, "N": 20, "launches_per_step": 2, **small,
+                                       "note": "10 loss rates x 20 runs x 250 steps, N = 20 (results_linear_system.py:64,147-149), "
+                                               "tmpc_mc_run: one solve launch + one state-machine launch per step"}
+            del mpc20
             # offline stage extra: support-function LPs over this workload's terminal set in one launch (tmpc_lp_batch)
             Xf = mpc._Xf
             dirs = np.random.default_rng(7).standard_normal((65536, Xf.A.shape[1]))
@@ -353,12 +435,28 @@ def main():
     stats_all = gather_stats()
     fence()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if use_pg:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     kern_ms, launches = _native.kernel_ms_total(h, reset=True)
+    # Evidence that the collective really joined `world` ranks, each on a GPU of its own: an all-reduce of ones, and every
+    # rank's own timed region and average kernel duration (outside the timed region)
+    ranks_seen, per_rank = 1, [[elapsed_local * 1e3 / args.steps, kern_ms / max(launches, 1), float(dev_index)]]
+    if use_pg:
+        cdev = dev if backend == "nccl" else "cpu"
+        ones = torch.ones(1, dtype=torch.float64, device=cdev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+        mine = torch.tensor(per_rank[0], dtype=torch.float64, device=cdev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [a.cpu().tolist() for a in allr]
+        if ranks_seen != world:
+            print(f"bench.py: the all-reduce saw {ranks_seen} ranks, expected {world}", file=sys.stderr)
+            sys.exit(4)
     # spread of the launch time over the eight batch orders (outside the timed region: one launch each, HIP events)
     _native.synchronize(h)
     _native.kernel_ms_total(h, reset=True)
@@ -397,6 +495,15 @@ def main():
                        "mean_ipm_iters": float(iters_all.mean()), "optimal_fraction": float((status_all == 0).mean()),
                        "trivial_fraction": float((iters_all == 0).mean())},
             "roofline": roof,
+            "ranks_seen": ranks_seen,
+            "per_rank_ms": {"ms_per_step": [r_[0] for r_ in per_rank], "avg_kernel_ms": [r_[1] for r_ in per_rank],
+                            "device_index": [int(r_[2]) for r_ in per_rank], "backend": backend if use_pg else "none",
+                            "note": "every rank's own timed region / K and average solve-kernel duration (HIP events); "
+                                    "ms_per_step above is the slowest rank's"},
+            # what the card ran between the set-up and the W warm-up steps (the headline depends on it by 2-4 %: clock ramp,
+            # scripts/gpu_ramp.py): "extras" = seconds of the other sections' launches, "none" = the set-up's idle time
+            "preload": ("none" if args.no_extras and (args.no_closed_loop or world > 1) else
+                        "extras" if not args.no_extras else "closed_loop"),
         }
         if world == 1 and not args.no_cpu_baseline:
             from oracle.oracle import Oracle
@@ -420,6 +527,16 @@ def main():
             out["cpu_baseline"]["single_thread"] = {"value": n1 / t1, "unit": "solves/s", "cores": 1, "kind": "port",
                                                     "sample": f"the first {n1} of those instances, one thread, {t1:.2f} s wall, "
                                                               f"mean iters {o1['iters'].mean():.2f}"}
+            # the reference's timing table for the CPU solver: 1000 single-QP calls on one thread (the oracle through ctypes)
+            tsc = []
+            for k in np.random.default_rng(11).integers(0, B, 1000):
+                a0 = time.perf_counter()
+                orc.solve(X[k:k + 1], R[k:k + 1], nthreads=1)
+                tsc.append(time.perf_counter() - a0)
+            out["cpu_baseline"]["single_call"] = dict(timing_table(tsc), calls=len(tsc), kind="port",
+                                                      note="oracle/tmpc_oracle.c, one QP per call, one thread")
+            if "single_call" in extras_out:
+                extras_out["single_call"]["cpu_oracle_one_thread"] = out["cpu_baseline"]["single_call"]
             # the reference's Monte-Carlo loop body (results_linear_system.py:209-291) on the host cores: numpy state
             # machines around the same CPU solver, all trajectories of a time step solved together
             def cpu_packets(x_hat, r, gamma=None):

@@ -212,7 +212,8 @@ int tmpc_debug_dump_lp_layout(int32_t d, int32_t nr, const double *H, const doub
  * results_linear_system_with_extendedMPC.py:247-378) -- controller packet, packet losses in both directions,
  * consistent actuator with nominal model and ancillary feedback (SmartActuator.py:125-231), plant update,
  * estimator / robust estimator (Estimator.py:9-161) -- run as per-trajectory state machines between the solve
- * launches, on the handle's stream; only the statistics return to the host.
+ * launches (one wavefront per trajectory, ONE launch per time step next to the solve's), on the handle's stream; only the
+ * statistics return to the host.
  *
  *   in   p_loss B        loss probability of the trajectory (both directions)
  *        ref    T        position reference; the solve gets ref_t = [ref[t], 0, ...]   (:240)
@@ -235,6 +236,22 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
                 const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
                 int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent,
                 int32_t *iters_sum);
+
+/*
+ * The state machines of tmpc_mc_run driven by GIVEN controller packets instead of solved ones -- the test entry that pins the
+ * device-side Estimator / RobustEstimator (Estimator.py:43-161) and SmartActuator / ConsistentActuator (SmartActuator.py:57-231)
+ * directly against trajectories recorded from the reference's classes (tests/golden/glue_golden.npz, glue_smart_golden.npz).
+ * Step t of trajectory b runs exactly the kernel tmpc_mc_run launches after its solve, with the packet
+ * U_pkt[b][t] = [u_0 .. u_{N-1} | terminal column] ((N+1) x nu, row per column of the reference's U_t) and, for the extended
+ * controller, x_nom_0 = xn0_pkt[b][t]; theta / gamma are the ARRIVAL flags of the two links (1 = arrives; step 0 always
+ * arrives, results_linear_system.py:211-214), w the disturbances, x0 the initial state (NULL: zeros).  No QP is solved.
+ *   out  trace_f  B*T*(3 nx + nu)   per step: x_{t+1}, x_hat_{t+1}, the nominal state in the plant's packet, u_t
+ *        trace_i  B*T*3             per step: s_t, Theta_t, and q_t as the controller's packet of step t carried it
+ * Actuator kind, plant and gains are the handle's (tmpc_mc_set_actuator, tmpc_mc_set_plant, K / K_anc of tmpc_problem).
+ * All pointers are HOST pointers.  Added without an ABI bump: a new export, nothing else changed.
+ */
+int tmpc_mc_replay(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *U_pkt, const double *xn0_pkt,
+                   const uint8_t *theta, const uint8_t *gamma, const double *w, const double *x0, double *trace_f, int32_t *trace_i);
 
 /*
  * Warm start inside tmpc_mc_run (off by default).  Consecutive QPs of a trajectory share most of their active set: with
@@ -337,6 +354,13 @@ int tmpc_kernel_ms_total(tmpc_handle *h, float *total_ms, int32_t *launches, int
  *   npar rows that depend on x_k only (checked once per instance, not iterated on)
  */
 int tmpc_get_dims(const tmpc_handle *h, int variant, int32_t *nv, int32_t *nc, int32_t *npar);
+/*
+ * How the nc rows are stored: nd general ("dense") rows of width nv and one block of ncc rows of rank kc kept in factored
+ * form Hc * Psi (the terminal set acts on [x_N; theta] only, TubeTrackingMPC.py:149; the initial-state set of the
+ * packet-received problem on x_0 only, :278); nc = nd + ncc, ncc = kc = 0 when nothing is factored.  bench.py prices the
+ * factored block at its rank in `roofline_factored`.  Added without an ABI bump: a new export, nothing else changed.
+ */
+int tmpc_get_factoring(const tmpc_handle *h, int variant, int32_t *nd, int32_t *ncc, int32_t *kc);
 
 /*
  * Copies the condensed, unscaled QP data of `variant` to caller buffers (any may be

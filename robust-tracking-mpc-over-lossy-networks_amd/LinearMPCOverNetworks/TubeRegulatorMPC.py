@@ -11,38 +11,9 @@ from __future__ import annotations
 import numpy as np
 
 from . import utils_polytope as up
+from .RegulatorMPC import RegulatorMPC
 from .control_lite import dlqr, dlyap
-from .polytope_lite import as_polytope, reduce
-
-
-class RegulatorMPC:
-    """State container + constraint setters (reference RegulatorMPC.py:11-43, :93)."""
-
-    def __init__(self, A, B, Q, R, N: int) -> None:
-        self._A = np.array(A, dtype=np.float64)
-        self._B = np.array(B, dtype=np.float64)
-        self._N = int(N)
-        self._nx = self._A.shape[1]
-        self._nu = self._B.shape[1]
-        self._Q = np.array(Q, dtype=np.float64)
-        self._R = np.atleast_2d(np.array(R, dtype=np.float64))
-        self._X = None
-        self._U = None
-        # the reference stores cp.CLARABEL here (RegulatorMPC.py:31); this build has
-        # exactly one back-end, the HIP library
-        self._solver = "hip"
-
-    def set_state_constraints(self, X) -> None:
-        self._X = as_polytope(X)
-
-    def set_input_constraints(self, U) -> None:
-        self._U = as_polytope(U)
-
-    def set_solver(self, solver) -> None:
-        """Reference RegulatorMPC.py:93-94.  Only the HIP back-end exists here."""
-        if str(solver).lower() not in ("hip", "clarabel"):
-            raise ValueError("this build solves on the MI355X only (solver='hip')")
-        self._solver = "hip"
+from .polytope_lite import reduce
 
 
 class TubeRegulatorMPC(RegulatorMPC):

@@ -105,6 +105,8 @@ def lib():
         L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_warm_start.restype = C.c_int
         L.tmpc_mc_run.restype = C.c_int
+        L.tmpc_mc_replay.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8
+        L.tmpc_mc_replay.restype = C.c_int
         L.tmpc_mc_set_actuator.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_actuator.restype = C.c_int
         L.tmpc_mc_set_plant.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int]
@@ -120,6 +122,8 @@ def lib():
         L.tmpc_kernel_ms_total.restype = C.c_int
         L.tmpc_get_dims.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
         L.tmpc_get_dims.restype = C.c_int
+        L.tmpc_get_factoring.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _ip]
+        L.tmpc_get_factoring.restype = C.c_int
         L.tmpc_get_condensed.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         L.tmpc_get_condensed.restype = C.c_int
         _lib = L
@@ -199,6 +203,14 @@ def get_dims(h: Handle, variant: int = 0):
     if lib().tmpc_get_dims(h.ptr, variant, C.byref(nv), C.byref(nc), C.byref(npar)) != 0:
         raise RuntimeError("tmpc_get_dims failed")
     return nv.value, nc.value, npar.value
+
+
+def get_factoring(h: Handle, variant: int = 0):
+    """include/tmpc.h: tmpc_get_factoring -> (general rows, rows of the factored block, its rank)."""
+    nd, ncc, kc = C.c_int32(), C.c_int32(), C.c_int32()
+    if lib().tmpc_get_factoring(h.ptr, variant, C.byref(nd), C.byref(ncc), C.byref(kc)) != 0:
+        raise RuntimeError("tmpc_get_factoring failed")
+    return nd.value, ncc.value, kc.value
 
 
 def get_condensed(h: Handle, variant: int = 0) -> dict:
@@ -378,6 +390,35 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
     out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve
     return out
+
+
+def mc_replay(h: Handle, U, theta, gamma, w, xn0=None, x0=None, extended: bool = False, smart: bool = False) -> dict:
+    """include/tmpc.h: tmpc_mc_replay -- the device-side estimator / actuator state machines driven by GIVEN controller
+    packets (no QP is solved).  U (B, T, N+1, nu): packets, terminal column last; theta, gamma (B, T): arrival flags;
+    w (B, T, nx); xn0 (B, T, nx) for the extended controller.  Returns per step x (state after the step), x_hat (estimate
+    after the step), x_nom (nominal state in the plant's packet), u (applied input), s, Theta, q."""
+    c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    U, w = c(U), c(w)
+    B, T = U.shape[:2]
+    if U.shape != (B, T, h.N + 1, h.nu) or w.shape != (B, T, h.nx):
+        raise ValueError("mc_replay: inconsistent shapes")
+    th = np.ascontiguousarray(np.asarray(theta).reshape(B, T) != 0, dtype=np.uint8)
+    ga = np.ascontiguousarray(np.asarray(gamma).reshape(B, T) != 0, dtype=np.uint8)
+    xn0c = None if xn0 is None else c(xn0).reshape(B, T, h.nx)
+    x0c = None if x0 is None else c(x0).reshape(B, h.nx)
+    tf = np.empty((B, T, 3 * h.nx + h.nu))
+    ti = np.empty((B, T, 3), np.int32)
+    mc_set_actuator(h, smart)
+    ptr = lambda a: None if a is None else a.ctypes.data
+    try:
+        rc = lib().tmpc_mc_replay(h.ptr, B, T, int(bool(extended)), ptr(U), ptr(xn0c), ptr(th), ptr(ga), ptr(w), ptr(x0c), ptr(tf), ptr(ti))
+    finally:
+        mc_set_actuator(h, False)
+    if rc != 0:
+        raise RuntimeError(f"tmpc_mc_replay failed ({rc}): {h.error()}")
+    nx = h.nx
+    return dict(x=tf[:, :, :nx], x_hat=tf[:, :, nx:2 * nx], x_nom=tf[:, :, 2 * nx:3 * nx], u=tf[:, :, 3 * nx:],
+                s=ti[:, :, 0], Theta=ti[:, :, 1], q=ti[:, :, 2])
 
 
 def lp_batch(H, h, Cmat, relax=None, relax_by: float = 1.0, device: int = 0, want_x: bool = False) -> dict:

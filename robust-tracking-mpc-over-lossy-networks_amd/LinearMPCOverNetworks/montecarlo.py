@@ -140,7 +140,7 @@ def draw_realisations_reference_order(p_loss, n_mc: int, T: int, w_bound, seeds=
 
 
 def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, ga_u, w, x0=None, extended: bool = False,
-                        plant=None, capture=None):
+                        plant=None, capture=None, observer=None):
     """Closed loop of the remote tube-based MPC over a lossy network for a batch of trajectories:
     the body of the reference's Monte-Carlo loop (results_linear_system.py:209-259, 291) with the
     per-trajectory objects replaced by the batched state machines and the QP solves of one time
@@ -156,6 +156,7 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
     e.g. workloads.cartpole_step for the nonlinear cart-pole of results_nonlinear_system.py.
     capture: index of one trajectory whose x_t, nominal state of the tube check and u_t are recorded (the scripts' sample run,
     :298-301) -> 'x_traj' (T, nx), 'x_nom_traj' (T, nx), 'u_traj' (T, nu).
+    observer: optional callable (t, {'s', 'Theta', 'u'}) called after the actuator of step t (copies of its s_t, Theta_t and u_t).
     Returns a dict of per-trajectory statistics."""
     from .Estimator import BatchedEstimator
     from .SmartActuator import BatchedConsistentActuator
@@ -202,6 +203,8 @@ def run_remote_tube_mpc(packets_fn, A, B, K, K_plant, N, Z, p_loss, ref, th_u, g
             est.store_x_nom_0(x_nom_0)                                                             # RLX:279
         x_nom_now = act.x_nom.copy()       # the nominal state the scripts test against: column t of x_nom_traj, i.e. BEFORE process_packet
         u, pkt = act.process(U_t, q_t, x, theta, x_nom_0 if extended else None)                    # :244
+        if observer is not None:
+            observer(t, dict(s=np.array(act.s).copy(), Theta=np.array(act.Theta).copy(), u=np.array(u).copy()))
         err2 += (x[:, 0] - ref_at(t)) ** 2 + np.sum(x[:, 1:] ** 2, axis=1)                            # :291 (x_t, t = 0..T-1)
         # :258 / results_linear_system_with_extendedMPC.py:310-318,331-333 -- x_traj[:, t] - x_nom_traj[:, t]: the nominal state
         # appended after the PREVIOUS step's process_packet, so for the extended controller the state before this step's

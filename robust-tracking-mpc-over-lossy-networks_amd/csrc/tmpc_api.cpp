@@ -432,7 +432,8 @@ int ensure_staging(tmpc_handle *h, int64_t B) {
 }
 
 int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
-            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int32_t *const *ws = nullptr) {
+            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int32_t *const *ws = nullptr,
+            bool variants_valid = false) {
     hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
     if (h->pool_used < 4096) {
         if (h->pool_used == h->pool.size()) {
@@ -447,7 +448,7 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     }
     h->ev0 = e0; h->ev1 = e1;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
-    if (variant != nullptr)
+    if (variant != nullptr && !variants_valid)      // (the closed loop's selector is its own gamma flags: always 0 or 1)
         HIP_TRY(h, tmpc::launch_mark_invalid_variants(variant, h->nvariants, B, h->nx, h->nu, h->N, u_nom, x_nom0, xu_ss, x_nom, status,
                                                       iters, h->stream));
     long long *ticks = nullptr;
@@ -836,12 +837,22 @@ int tmpc_mc_set_warm_start(tmpc_handle *h, int on) {
     return TMPC_OK;
 }
 
-int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
+}  // extern "C"
+
+namespace {
+// packets injected by the caller (tmpc_mc_replay) and the per-step record that goes back
+struct McReplay {
+    const double *U, *xn0;      // host: [B][T][N+1][nu], [B][T][nx] (xn0 may be NULL unless extended)
+    double *trace_f;            // host: [B][T][3 nx + nu]
+    int32_t *trace_i;           // host: [B][T][3]
+};
+
+int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
                 const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
                 int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent,
-                int32_t *iters_sum) {
+                int32_t *iters_sum, const McReplay *rp) {
     if (!h) return TMPC_E_INVALID;
-    const bool host_draws = !h->mc_rng_on;
+    const bool host_draws = rp != nullptr || !h->mc_rng_on;
     if (B < 0 || T < 0 || !p_loss || !ref || (host_draws && (!th_u || !ga_u || !w)) || (rZ > 0 && (!HZ || !hZ))) { h->err = "tmpc_mc_run: NULL argument"; return TMPC_E_INVALID; }
     if (h->device < 0) { h->err = "host-only handle (device < 0): nothing can be solved without the GPU"; return TMPC_E_DEVICE; }
     if (extended && h->nvariants < 2) { h->err = "tmpc_mc_run: extended loop needs a problem created with extended = 1"; return TMPC_E_INVALID; }
@@ -853,8 +864,9 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     if (rc) return rc;
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
-    const size_t need = 256 * 40 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
-                        8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu);
+    const size_t need = 256 * 48 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
+                        8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu) +
+                        (rp ? b * t_ * (8 * ((N + 1) * nu + nx) + 8 * (3 * nx + nu) + 4 * 3) : 0);
     // what the previous run left in the arena is gone from here on, whether this run gets as far as replacing it or not
     // (tmpc_mc_get_capture / _solve_ticks / _physics_error must not read a freed or half-written arena)
     h->mc_cap_dev = nullptr; h->mc_cap_T = 0;
@@ -912,7 +924,7 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             {reinterpret_cast<void **>(&st.x), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.x_hat), b * nx * 8, 0},
             {reinterpret_cast<void **>(&st.x_nom), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.Ubuf), b * (N + 1) * nu * 8, 0},
             {reinterpret_cast<void **>(&st.u_latest0), b * nu * 8, 0}, {reinterpret_cast<void **>(&st.x_nom0_latest), b * nx * 8, 0},
-            {reinterpret_cast<void **>(&st.ref_k), b * nx * 8, 0}, {reinterpret_cast<void **>(&st.e_buf), b * nx * 8, 0},
+            {reinterpret_cast<void **>(&st.ref_k), b * nx * 8, 0},
             {reinterpret_cast<void **>(&st.err2), b * 8, 0},
             {reinterpret_cast<void **>(&st.consistent), b * 8, 0}, {reinterpret_cast<void **>(&st.q_est), b * 4, 0},
             {reinterpret_cast<void **>(&st.q_act), b * 4, 0}, {reinterpret_cast<void **>(&st.s), b * 4, 0},
@@ -964,13 +976,35 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
                 HIP_TRY(h, hipMemsetAsync(ws[k], 0, b * tmpc::WS_STRIDE * 4, h->stream));
             }
         }
+        if (rp) {
+            if ((r2 = up(rp->U, b * t_ * (N + 1) * nu * 8, reinterpret_cast<const void **>(&st.rp_U)))) return r2;
+            if (rp->xn0) { if ((r2 = up(rp->xn0, b * t_ * nx * 8, reinterpret_cast<const void **>(&st.rp_xn0)))) return r2; }
+            else {
+                // (plain controller: the packets carry no x_nom_0; the state machines then never read it -- zeros)
+                void *z = nullptr;
+                if ((r2 = dalloc(b * t_ * nx * 8, &z))) return r2;
+                HIP_TRY(h, hipMemsetAsync(z, 0, b * t_ * nx * 8, h->stream));
+                st.rp_xn0 = static_cast<const double *>(z);
+            }
+            if ((r2 = dalloc(b * t_ * (3 * nx + nu) * 8, reinterpret_cast<void **>(&st.trace_f)))) return r2;
+            if ((r2 = dalloc(b * t_ * 3 * 4, reinterpret_cast<void **>(&st.trace_i)))) return r2;
+            HIP_TRY(h, hipMemsetAsync(st.trace_f, 0, b * t_ * (3 * nx + nu) * 8, h->stream));
+            HIP_TRY(h, hipMemsetAsync(st.trace_i, 0, b * t_ * 3 * 4, h->stream));
+        }
+        // Per time step: the solve launch(es) -- one per problem variant in use -- and ONE launch of the state machines
+        // (round 3: mc_pre, the variant check, the solve, mc_post, mc_tube).  With injected packets nothing is solved.
+        HIP_TRY(h, tmpc::launch_mc_pre(m, st, B, ref[0], h->stream));
         for (int t = 0; t < T; ++t) {
-            HIP_TRY(h, tmpc::launch_mc_pre(m, st, t, B, ref[t], h->stream));
-            int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it, ws);
-            if (r3) return r3;
-            st.ticks = h->want_ticks ? h->d_ticks : nullptr;       // (allocated by the first enqueue)
-            HIP_TRY(h, tmpc::launch_mc_post(m, st, t, T, B, ref[t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, h->stream));
-            HIP_TRY(h, tmpc::launch_mc_tube(m, st, B, h->stream));
+            if (!rp) {
+                int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it, ws, true);
+                if (r3) return r3;
+                st.ticks = h->want_ticks ? h->d_ticks : nullptr;       // (allocated by the first enqueue)
+            }
+            HIP_TRY(h, tmpc::launch_mc_step(m, st, t, T, B, ref[t], ref[t + 1 < T ? t + 1 : t], h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, h->stream));
+        }
+        if (rp) {
+            HIP_TRY(h, hipMemcpyAsync(rp->trace_f, st.trace_f, b * t_ * (3 * nx + nu) * 8, hipMemcpyDeviceToHost, h->stream));
+            HIP_TRY(h, hipMemcpyAsync(rp->trace_i, st.trace_i, b * t_ * 3 * 4, hipMemcpyDeviceToHost, h->stream));
         }
         if (err2) HIP_TRY(h, hipMemcpyAsync(err2, st.err2, b * 8, hipMemcpyDeviceToHost, h->stream));
         if (tube_viol) HIP_TRY(h, hipMemcpyAsync(tube_viol, st.tube_viol, b * 4, hipMemcpyDeviceToHost, h->stream));
@@ -984,6 +1018,30 @@ int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     rc = run();
     if (rc != TMPC_OK) (void)hipStreamSynchronize(h->stream);
     return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int tmpc_mc_run(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *p_loss, const double *ref,
+                const double *th_u, const double *ga_u, const double *w, const double *x0, const double *HZ, const double *hZ,
+                int32_t rZ, double *err2, int32_t *tube_viol, int32_t *not_optimal, double *x_final, double *consistent,
+                int32_t *iters_sum) {
+    return mc_run_impl(h, B, T, extended, p_loss, ref, th_u, ga_u, w, x0, HZ, hZ, rZ, err2, tube_viol, not_optimal, x_final, consistent,
+                       iters_sum, nullptr);
+}
+
+int tmpc_mc_replay(tmpc_handle *h, int64_t B, int32_t T, int extended, const double *U_pkt, const double *xn0_pkt,
+                   const uint8_t *theta, const uint8_t *gamma, const double *w, const double *x0, double *trace_f, int32_t *trace_i) {
+    if (!h) return TMPC_E_INVALID;
+    if (B < 0 || T < 0 || !U_pkt || !theta || !gamma || !w || !trace_f || !trace_i || (extended && !xn0_pkt)) { h->err = "tmpc_mc_replay: NULL argument"; return TMPC_E_INVALID; }
+    // arrival flags as uniforms against a loss rate of one half: lost iff t > 0 and uniform < 1/2 (the draw rule of tmpc_mc_run)
+    const size_t n = static_cast<size_t>(B) * static_cast<size_t>(T);
+    std::vector<double> th(n), ga(n), pl(static_cast<size_t>(B), 0.5), ref(static_cast<size_t>(T), 0.0);
+    for (size_t i = 0; i < n; ++i) { th[i] = theta[i] ? 1.0 : 0.0; ga[i] = gamma[i] ? 1.0 : 0.0; }
+    McReplay rp{U_pkt, xn0_pkt, trace_f, trace_i};
+    return mc_run_impl(h, B, T, extended, pl.data(), ref.data(), th.data(), ga.data(), w, x0, nullptr, nullptr, 0, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, &rp);
 }
 
 int tmpc_synchronize(tmpc_handle *h) {
@@ -1033,6 +1091,15 @@ int tmpc_get_dims(const tmpc_handle *h, int variant, int32_t *nv, int32_t *nc, i
     if (nv) *nv = c.nv;
     if (nc) *nc = c.nc;
     if (npar) *npar = c.npar;
+    return TMPC_OK;
+}
+
+int tmpc_get_factoring(const tmpc_handle *h, int variant, int32_t *nd, int32_t *ncc, int32_t *kc) {
+    if (!h || variant < 0 || variant >= h->nvariants) return TMPC_E_INVALID;
+    const tmpc::Condensed &c = h->v[variant].c;
+    if (nd) *nd = c.nd;
+    if (ncc) *ncc = c.ncc;
+    if (kc) *kc = c.kc;
     return TMPC_OK;
 }
 

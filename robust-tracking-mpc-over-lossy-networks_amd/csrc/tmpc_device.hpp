@@ -137,7 +137,6 @@ struct McState {                         // all [trajectory]-major device arrays
     double *Ubuf;                        // sequence buffered by the actuator                                  [B][N+1][nu]
     double *u_latest0, *x_nom0_latest;   // first input / x_nom_0 of the last sequence sent                    [B][nu], [B][nx]
     double *ref_k;                       // reference handed to the solve                                       [B][nx]
-    double *e_buf;                       // x_t - x_nom_t of the current step, for the tube membership kernel    [B][nx]
     double *err2, *consistent;           // statistics                                                          [B]
     double *err2_phys;                   // sum of |x - ref|^2 over the physics steps of a nonlinear plant (or nullptr)  [B]
     int32_t *q_est, *q_act, *s, *Theta, *last_lost, *tube_viol, *not_optimal, *iters_sum;
@@ -154,13 +153,19 @@ struct McState {                         // all [trajectory]-major device arrays
     long long *tick_sum, *tick_max;           // their sum and maximum along the trajectory (with ticks)                 [B]
     long long cap_index;                      // trajectory whose states are recorded (-1: none)
     double *cap;                              // [T][2 nx + nu]: x_t, the nominal state the tube check uses, u_t
+    // packet injection (tmpc_mc_replay): the controller's packets come from the caller instead of from a solve, and every
+    // step of every trajectory is recorded
+    const double *rp_U;                       // [B][T][N+1][nu] packets U_t (terminal column included), or nullptr: solved packets
+    const double *rp_xn0;                     // [B][T][nx]      x_nom_0 of the packets (extended controller)
+    double *trace_f;                          // [B][T][3 nx + nu]: x_{t+1}, x_hat_{t+1}, nominal state of the plant's packet, u_t; or nullptr
+    int32_t *trace_i;                         // [B][T][3]: s_t, Theta_t, q_t (the controller's packet)
 };
 hipError_t launch_mark_invalid_variants(const uint8_t *variant, int nvariants, int64_t B, int nx, int nu, int N, double *u_nom,
                                         double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters,
                                         hipStream_t stream);
-hipError_t launch_mc_pre(const McModel &m, const McState &st, int t, int64_t B, double ref_t, hipStream_t stream);
-hipError_t launch_mc_tube(const McModel &m, const McState &st, int64_t B, hipStream_t stream);
-hipError_t launch_mc_post(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, const double *u_nom,
+// one launch before the first solve (reference of step 0), then one launch per time step after the solve launch(es)
+hipError_t launch_mc_pre(const McModel &m, const McState &st, int64_t B, double ref_0, hipStream_t stream);
+hipError_t launch_mc_step(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, double ref_next, const double *u_nom,
                           const double *x_nom0, const double *xu_ss, const int32_t *status, const int32_t *iters, hipStream_t stream);
 
 // LP kernel (tmpc_lp.hip): rows scaled to unit norm, h scaled by hm so that max |h| = 1

@@ -89,6 +89,36 @@ def test_closed_loop_gpu_matches_oracle_loop(hip_lib, oracle_lib, extended):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("extended,N", [(False, 10), (True, 10), (False, 20), (True, 20)])
+def test_device_loop_at_p_loss_09_plays_the_buffered_tail_like_the_oracle_loop(hip_lib, oracle_lib, extended, N):
+    """Nine packets in ten are lost in both directions: the actuator plays u_1 .. u_{N-1} of its buffered sequence and the
+    terminal law past its end (SmartActuator.py:100-103), so the LATER inputs of every solve reach the plant.  The
+    device-resident loop (device solver + device state machines) against the numpy loop driven by the CPU oracle, same
+    realisations: final states to 1e-7, and the buffer really is played to its end."""
+    nb, T = 48, 120
+    mpc, w = common.make_mpc("cartpole", N, True, extended=extended)
+    mpc_gpu, _ = common.make_mpc("cartpole", N, True, extended=extended, create=True)
+    p_loss = np.full(nb, 0.9)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=90 + N)
+    ref = np.where(np.arange(T) < T // 2, 0.5, -0.3)
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    orc = Oracle(mpc._problem_dict())
+    seen_d = []
+    host = montecarlo.run_remote_tube_mpc(_oracle_packets(mpc, orc), w["A"], w["B"], K, Kp, N, mpc._Z, p_loss, ref, th, ga, dist,
+                                          extended=extended, observer=lambda t, st: seen_d.append(t - st["s"]))
+    dev = mpc_gpu.run_closed_loop(p_loss, ref, th, ga, dist, extended=extended)
+    d = np.array(seen_d)
+    assert d.max() >= N and (d >= 1).mean() > 0.7          # most steps play a later input, some run past the sequence
+    assert np.all(dev["not_optimal"] == 0) and np.all(host["not_optimal"] == 0)
+    assert np.array_equal(dev["tube_violations"], host["tube_violations"]) and np.all(dev["tube_violations"] == 0)
+    err = float(np.max(np.abs(dev["x_final"] - host["x_final"])))
+    print(f"p_loss 0.9, N = {N}, extended = {extended}: max |x_final(device loop) - x_final(oracle loop)| = {err:.2e}, "
+          f"longest run on one buffered sequence {int(d.max())} steps")
+    assert err <= 1e-7, err
+    np.testing.assert_allclose(dev["tracking_error"], host["tracking_error"], atol=1e-9, rtol=0)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("extended", [False, True])
 def test_device_resident_loop_equals_host_loop(hip_lib, extended):
     """tmpc_mc_run (state machines in HIP between the solve launches) against the numpy state machines driving

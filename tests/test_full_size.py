@@ -76,9 +76,11 @@ def test_config3_extended_gamma_mix_at_65536(hip_lib, oracle_lib):
     # (see test_hard_packet_received_states_certify_on_the_device): 1e-5 there
     du0 = np.abs(out["u_nom"][sub][ok][:, 0] - ref["u_nom"][ok][:, 0])
     assert np.max(du0) < 1e-7 and np.mean(du0 < 1e-8) > 0.995, (np.max(du0), np.mean(du0 < 1e-8))     # (one instance in 1 500 at 2e-8)
-    np.testing.assert_allclose(out["u_nom"][sub][ok], ref["u_nom"][ok], rtol=0, atol=1e-5)
+    # the buffered tail u_1 .. u_19 is what the actuator plays after a packet loss (SmartActuator.py:100-103): measured, printed, bounded
+    tail_vs_oracle = float(np.max(np.abs(out["u_nom"][sub][ok][:, 1:] - ref["u_nom"][ok][:, 1:])))
+    assert tail_vs_oracle <= 1e-5, tail_vs_oracle
     tpl = {v: qp_sparse.SparseTemplate(p, v) for v in (0, 1)}
-    worst = 0.0
+    worst, worst_tail = 0.0, 0.0
     for k in sub[:96]:
         if st[k] != 0:
             continue
@@ -87,8 +89,12 @@ def test_config3_extended_gamma_mix_at_65536(hip_lib, oracle_lib):
         d = qp_sparse.minimiser_distance(qp, v)
         assert d["certified"] and d["du0"] <= 1e-8, (k, d["du0"], d["certified"])
         worst = max(worst, d["du0"])
+        L = qp["layout"]
+        worst_tail = max(worst_tail, float(np.max(np.abs(d["dv"][L.ou:L.oxb]))))
+    assert worst_tail <= 1e-5, worst_tail        # every input of the sequence against the EXACT minimiser, not only u_0
     print(f"config 3 at {B}: {good.sum()} optimal, {int((st == 2).sum())} infeasible, {len(odd)} uncertified; "
-          f"worst distance of u_0 from the exact minimiser on a sample of 96: {worst:.2e}")
+          f"worst distance of u_0 from the exact minimiser on a sample of 96: {worst:.2e}; of any u_i: {worst_tail:.2e}; "
+          f"max |u_i - oracle|, i >= 1, over {int(ok.sum())} instances: {tail_vs_oracle:.2e}")
 
 
 def test_config5_at_16384(hip_lib, oracle_lib):
@@ -156,10 +162,17 @@ def test_hard_packet_received_states_certify_on_the_device(hip_lib, oracle_lib):
     # facets: a working row may be off its bound by 1e-11 of its right-hand side, which those facets amplify to a few 1e-6 in
     # u_5 ... u_19 (cost excess 1e-13 relative).  Device, oracle and the exact active-set solve differ there by that much.
     np.testing.assert_allclose(out["u_nom"][:, 0], ref["u_nom"][:, 0], rtol=0, atol=1e-8)
-    np.testing.assert_allclose(out["u_nom"], ref["u_nom"], rtol=0, atol=1e-4)
+    tail_vs_oracle = float(np.max(np.abs(out["u_nom"][:, 1:] - ref["u_nom"][:, 1:])))
     tpl = {v: qp_sparse.SparseTemplate(p, v) for v in (0, 1)}
+    tail_vs_exact = 0.0
     for k in range(len(X)):
         qp = tpl[int(G[k])].instance(X[k], R[k])
         v = qp_sparse.pack(qp, out["x_nom"][k], out["u_nom"][k], out["x_ss"][k], out["u_ss"][k])
         d = qp_sparse.minimiser_distance(qp, v)
         assert d["certified"] and d["du0"] <= 1e-8, (k, d["du0"])
+        L = qp["layout"]
+        tail_vs_exact = max(tail_vs_exact, float(np.max(np.abs(d["dv"][L.ou:L.oxb]))))
+    print(f"hard packet-received states: max |u_i - oracle|, i >= 1: {tail_vs_oracle:.2e}; max |u_i - exact minimiser| over the "
+          f"whole sequence: {tail_vs_exact:.2e}")
+    assert tail_vs_oracle <= 2e-5, tail_vs_oracle
+    assert tail_vs_exact <= 2e-5, tail_vs_exact

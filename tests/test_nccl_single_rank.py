@@ -79,3 +79,21 @@ def test_bench_timed_loop_with_a_process_group():
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     line = json.loads(res.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 1e6 and line["config"]["optimal_fraction"] == 1.0
+    # the line proves by itself that the collective joined the ranks it claims (here: one) and what each of them measured
+    assert line["ranks_seen"] == 1
+    pr = line["per_rank_ms"]
+    assert pr["backend"] == "nccl" and pr["device_index"] == [0]
+    assert len(pr["ms_per_step"]) == 1 and len(pr["avg_kernel_ms"]) == 1
+    assert 0.0 < pr["avg_kernel_ms"][0] <= pr["ms_per_step"][0] <= line["ms_per_step"] * 1.0001
+    assert line["preload"] == "none"
+
+
+def test_bench_refuses_more_nccl_ranks_than_gpus():
+    """Two ranks announced on a one-GPU box: a clear message and exit code 3 before any process group is set up."""
+    env = dict(_env(29544), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs")
+    assert res.returncode == 3 and "RCCL needs one GPU per rank" in res.stderr, res.stderr[-2000:]
