@@ -190,16 +190,19 @@ const char *tmpc_kernel_name(const tmpc_handle *h, int variant);
 
 /*
  * Diagnostics (tests/wavesim: the kernel sources compiled for the CPU under sanitizers): writes to `path` everything the
- * wave-per-QP kernel receives for `variant` -- the compiled shape (NVP, DP, DS, KC, CP, CS; int32 x 6), the size of
- * tmpc::DeviceQP (csrc/tmpc_device.hpp; uint64) and the structure itself, then, for each of its arrays in field order
- * (Gt, Hct, Psi, Hs, Hinv, F1s, F2s, g0p, Esp, vmask, row_of, gp0, Ep, Dv, Tzs, Txf, Mth, A, B), a uint64 byte count and
- * the bytes.  Host-only handles (device < 0) only: TMPC_E_UNSUPPORTED otherwise, or when no wave shape covers the variant.
- * Not part of the solve path.
+ * wave-per-QP kernel receives for `variant` -- two int32 words {tag "TMPC" = 0x43504d54, dump format = tmpc::DUMP_FORMAT of
+ * csrc/tmpc_device.hpp, bumped with every change of the records below: a reader built against another format must reject the
+ * file}, the compiled shape (NVP, DP, DS, KC, CP, CS; int32 x 6), the size of tmpc::DeviceQP (csrc/tmpc_device.hpp; uint64)
+ * and the structure itself, then, for each of its arrays in field order (Gt, Hct, Psi, Hs, Hinv, F1s, F2s, g0p, Esp, vmask,
+ * row_of, gp0, Ep, Dv, Tzs, Txf, Mth, A, B, cip), a uint64 byte count and the bytes.  Host-only handles (device < 0) only:
+ * TMPC_E_UNSUPPORTED otherwise, or when no wave shape covers the variant.  Not part of the solve path.
  */
 int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path);
-/* The same for the workgroup-per-QP kernel: tiles and workspace rows (int32 x 2), the sizes of tmpc::DeviceQP and
- * tmpc::BlockQP (uint64 x 2), the two structures, then the arrays Hs, Hinv, F1s, F2s, gp0, Ep, Dv, Tzs, Txf, Mth, A, B of the
- * first and Grm, Gcm, GHrm, g0, Es, ncols of the second, each as a uint64 byte count and the bytes. */
+/* The same for the workgroup-per-QP kernel: the two format words, tiles and workspace rows (int32 x 2), the sizes of
+ * tmpc::DeviceQP and tmpc::BlockQP (uint64 x 2), the two structures (BlockQP as of format 2: ncp, nz4, zx0, znx, mir, ng, ngp, the
+ * array pointers, row_start[9]), then 20 records, each a uint64 byte count and the bytes: Hs, Hinv, F1s, F2s, gp0, Ep, Dv, Tzs,
+ * Txf, Mth, A, B of the first structure; Grm ([ngp + NVP][NVP]: the rows of G, then the NVP rows of Hs), Gcm, GHrm, g0, Es,
+ * ncols of the second; Gw ([ncp][NVP], G by constraint row) -- zero bytes when Gw is Grm (mir == 0); and ci ([ncp], format 3). */
 int tmpc_debug_dump_block_layout(const tmpc_handle *h, int variant, const char *path);
 /* The same for the batched LP kernel (tmpc_lp_batch): the polytope (H, h) in kernel units -- int32 d, nr, nrp, DP (padded
  * dimension), max_iter; double tol, relax_by, hm; then H transposed [DP][nrp], h [nrp] and the row scale [nrp].  No device

@@ -370,6 +370,19 @@ def minimiser_distance(qp: dict, v: np.ndarray, active=None, act_tol: float = 1e
             active = np.delete(active, int(np.argmin(mu_in)))
             continue
         break
+    if d is not None and d["certified"] and len(d["mu_in"]) and float(np.max(np.abs(d["dv"]))) > 1e-9:
+        # A row within act_tol of its bound that is NOT active at the minimiser, kept in the set with a zero multiplier (the
+        # bounded least-squares fit above puts it there): stationarity holds only to the certificate's 1e-7 |q| -- 0.1 in
+        # absolute terms for the cart-pole -- and the point found is the minimiser on too small a face (seen: u_2 off by
+        # 0.1 with a HIGHER objective than the candidate).  Rows that carry no multiplier are not needed to hold the
+        # minimiser: without them the face is larger, and if its minimiser certifies with an objective no higher, it is
+        # the better answer.
+        mu_in = d["mu_in"]
+        keep = mu_in > 1e-9 * max(1.0, float(np.abs(mu_in).max()))
+        if not keep.all():
+            d2 = _minimiser_on_set(qp, v, active[keep])
+            if d2["certified"] and objective(qp, v + d2["dv"]) <= objective(qp, v + d["dv"]):
+                d, active = d2, active[keep]
     d["active"] = active
     return d
 

@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG, "lib", "libtmpc_hip.so")
+# (TMPC_LIB: another build of the same library, e.g. a diagnostic variant -- developers' A/B runs; default: the in-tree build)
+LIB_PATH = os.environ.get("TMPC_LIB") or os.path.join(_PKG, "lib", "libtmpc_hip.so")
 ABI_VERSION = 5
 
 _PTR_FIELDS = ["A", "B", "Q", "R", "P", "T", "K", "K_anc",

@@ -160,6 +160,22 @@ int upload_common(tmpc_handle *h, Variant &v, const tmpc_problem &p, tmpc::Devic
     return TMPC_OK;
 }
 
+// 1 / (g_r Hs^-1 g_r') for every row of the scaled problem: the multiplier of the QP with row r alone is (violation of row r at
+// the unconstrained minimiser) times this -- the scale of the multipliers the interior-point phase starts from
+std::vector<double> single_row_curvature_inv(const tmpc::Condensed &c) {
+    std::vector<double> ci(c.nc, 0.0), t(c.nv);
+    for (int r = 0; r < c.nc; ++r) {
+        double q = 0.0;
+        for (int i = 0; i < c.nv; ++i) {
+            double v = 0.0;
+            for (int j = 0; j < c.nv; ++j) v += c.Hinv(i, j) * c.Gs(r, j);
+            q += v * c.Gs(r, i);
+        }
+        ci[r] = q > 0.0 ? 1.0 / q : 0.0;
+    }
+    return ci;
+}
+
 // one-wave-per-QP path (tmpc_kernels.hip): functionals (a row and, where it exists, its mirror row) in 64-wide slots of four
 // kinds -- dense paired, dense single, factored paired, factored single -- and per row side the right-hand side data
 int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
@@ -196,12 +212,15 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     const int kc = use_fact ? c.kc : 0;
     const int LDG = 16 * ((NVP + 1 + 15) / 16) + 1;        // Shape::LDG of tmpc_kernels.hip
     std::vector<double> Gt(static_cast<size_t>(NDP) * LDG + 1, 0.0), Hct(static_cast<size_t>(KCP) * NCCP + 1, 0.0),
-        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), g0p(static_cast<size_t>(RS) * 64, 1.0), Esp(static_cast<size_t>(RS) * 64 * nx, 0.0);
+        Psi(static_cast<size_t>(KCP) * NVP + 1, 0.0), g0p(static_cast<size_t>(RS) * 64, 1.0), Esp(static_cast<size_t>(RS) * 64 * nx, 0.0),
+        cip(static_cast<size_t>(RS) * 64, 0.0);
+    const std::vector<double> ci_rows = single_row_curvature_inv(c);
     std::vector<uint32_t> vmask(64, 0u);
     std::vector<int32_t> row_of(static_cast<size_t>(RS) * 64, -1);
     auto put_side = [&](int side, int lane, int row) {
         const size_t sl = static_cast<size_t>(side) * 64 + lane;
         g0p[sl] = c.g0s[row];
+        cip[sl] = ci_rows[row];
         for (int j = 0; j < nx; ++j) Esp[static_cast<size_t>(j) * RS * 64 + sl] = c.Es(row, j);
         vmask[lane] |= 1u << side;
         row_of[sl] = row;
@@ -251,6 +270,7 @@ int upload_wave(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload(h, v, Psi.data(), Psi.size(), &d.Psi))) return rc;
     if ((rc = upload(h, v, g0p.data(), g0p.size(), &d.g0p))) return rc;
     if ((rc = upload(h, v, Esp.data(), Esp.size(), &d.Esp))) return rc;
+    if ((rc = upload(h, v, cip.data(), cip.size(), &d.cip))) return rc;
     if ((rc = upload(h, v, vmask.data(), vmask.size(), &d.vmask))) return rc;
     if ((rc = upload(h, v, row_of.data(), row_of.size(), &d.row_of))) return rc;
 #ifdef TMPC_STAMPS
@@ -306,6 +326,8 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
             Grm[static_cast<size_t>(ngp + i) * NVP + j] = (i < c.nv && j < c.nv) ? c.Hs(i, j) : (i == j ? 1.0 : 0.0);
     std::vector<double> Gw(paired ? static_cast<size_t>(ncp) * NVP : 0, 0.0), GH(static_cast<size_t>(ncp) * NVP, 0.0);
     std::vector<int32_t> ncols(ngp, c.nv);
+    std::vector<double> ci(ncp, 0.0);
+    const std::vector<double> ci_rows = single_row_curvature_inv(c);
     for (int t = 0; t <= 8; ++t) v.bq.row_start[t] = ng;
     for (int rr = ng - 1; rr >= nz4; --rr)
         for (int t = 0; t < ext[order[rr]] && t <= 8; ++t) v.bq.row_start[t] = rr;
@@ -329,17 +351,19 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
             }
         }
         g0[rr] = c.g0s[r];
+        ci[rr] = ci_rows[r];
         for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(rr) * nx + j] = c.Es(r, j);
         if (paired) {
             const int q = c.mirror[r];
             g0[rr + mir] = c.g0s[q];
+            ci[rr + mir] = ci_rows[q];
             for (int j = 0; j < nx; ++j) Es[static_cast<size_t>(rr + mir) * nx + j] = c.Es(q, j);
         }
     }
     int rc;
     if ((rc = upload_common(h, v, p, v.db, NVP))) return rc;
     v.db.nd = c.nc; v.db.ncc = 0; v.db.kc = 0; v.db.nks = 0;
-    v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = nullptr;
+    v.db.Gt = v.db.Hct = v.db.Psi = v.db.g0p = v.db.Esp = v.db.cip = nullptr;
     v.db.vmask = nullptr; v.db.row_of = nullptr;
     v.bq.ncp = ncp;
     v.bq.nz4 = nz4;
@@ -354,6 +378,7 @@ int upload_block(tmpc_handle *h, Variant &v, const tmpc_problem &p) {
     if ((rc = upload(h, v, g0.data(), g0.size(), &v.bq.g0))) return rc;
     if ((rc = upload(h, v, Es.data(), Es.size(), &v.bq.Es))) return rc;
     if ((rc = upload(h, v, ncols.data(), ncols.size(), &v.bq.ncols))) return rc;
+    if ((rc = upload(h, v, ci.data(), ci.size(), &v.bq.ci))) return rc;
 #ifdef TMPC_STAMPS
     {
         void *dbgp = nullptr;
@@ -586,7 +611,13 @@ int tmpc_create(const tmpc_problem *p, int device, tmpc_handle **out) {
             }
         }
         if (rc == TMPC_OK && device < 0) {
-            for (int k = 0; k < h->nvariants && rc == TMPC_OK; ++k) rc = upload_variant(h, h->v[k], *p);
+            // host-only handle: the layouts are laid out for the debug dumps only.  A problem no kernel covers (nv > 128) still
+            // gets its handle -- tmpc_get_condensed and the oracle-side tests use it -- and the dump calls answer UNSUPPORTED
+            // (wave_ok = false, tiles = 0).
+            for (int k = 0; k < h->nvariants && rc == TMPC_OK; ++k) {
+                rc = upload_variant(h, h->v[k], *p);
+                if (rc == TMPC_E_UNSUPPORTED) { rc = TMPC_OK; h->err.clear(); }
+            }
         }
     } catch (const std::exception &ex) {
         h->err = std::string("tmpc_create: ") + ex.what();
@@ -687,12 +718,14 @@ int tmpc_debug_dump_layout(const tmpc_handle *h, int variant, const char *path) 
     if (!f) return TMPC_E_INVALID;
     const int32_t shp[6] = {v.shape.nvp, v.shape.dp, v.shape.ds, v.shape.kcp, v.shape.cp, v.shape.cs};
     const uint64_t qp_bytes = sizeof(tmpc::DeviceQP);
+    const int32_t tag[2] = {tmpc::DUMP_TAG, tmpc::DUMP_FORMAT};
+    std::fwrite(tag, 4, 2, f);
     std::fwrite(shp, 4, 6, f);
     std::fwrite(&qp_bytes, 8, 1, f);
     std::fwrite(&v.d, sizeof(tmpc::DeviceQP), 1, f);
     // every array the structure points to, in the order of its fields: byte count, bytes (0: null pointer)
     const void *ptrs[] = {v.d.Gt, v.d.Hct, v.d.Psi, v.d.Hs, v.d.Hinv, v.d.F1s, v.d.F2s, v.d.g0p, v.d.Esp, v.d.vmask, v.d.row_of,
-                          v.d.gp0, v.d.Ep, v.d.Dv, v.d.Tzs, v.d.Txf, v.d.Mth, v.d.A, v.d.B};
+                          v.d.gp0, v.d.Ep, v.d.Dv, v.d.Tzs, v.d.Txf, v.d.Mth, v.d.A, v.d.B, v.d.cip};
     for (const void *q : ptrs) {
         uint64_t n = 0;
         if (q)
@@ -714,12 +747,14 @@ int tmpc_debug_dump_block_layout(const tmpc_handle *h, int variant, const char *
     if (!f) return TMPC_E_INVALID;
     const int32_t hd[2] = {v.tiles, tmpc::block_workspace_rows()};
     const uint64_t sz[2] = {sizeof(tmpc::DeviceQP), sizeof(tmpc::BlockQP)};
+    const int32_t tag[2] = {tmpc::DUMP_TAG, tmpc::DUMP_FORMAT};
+    std::fwrite(tag, 4, 2, f);
     std::fwrite(hd, 4, 2, f);
     std::fwrite(sz, 8, 2, f);
     std::fwrite(&v.db, sizeof(tmpc::DeviceQP), 1, f);
     std::fwrite(&v.bq, sizeof(tmpc::BlockQP), 1, f);
     const void *ptrs[] = {v.db.Hs, v.db.Hinv, v.db.F1s, v.db.F2s, v.db.gp0, v.db.Ep, v.db.Dv, v.db.Tzs, v.db.Txf, v.db.Mth, v.db.A, v.db.B,
-                          v.bq.Grm, v.bq.Gcm, v.bq.GHrm, v.bq.g0, v.bq.Es, v.bq.ncols, v.bq.Gw == v.bq.Grm ? nullptr : v.bq.Gw};
+                          v.bq.Grm, v.bq.Gcm, v.bq.GHrm, v.bq.g0, v.bq.Es, v.bq.ncols, v.bq.Gw == v.bq.Grm ? nullptr : v.bq.Gw, v.bq.ci};
     for (const void *q : ptrs) {
         uint64_t n = 0;
         if (q)

@@ -964,10 +964,17 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
             // ------------------------------------------------------------ interior point
             {
                 const double fl = 0.1 * fmax(-smin, 1.0);
+                // starting multipliers: the fourth root of the largest single-row multiplier viol_r / (g_r Hs^-1 g_r') over the
+                // violated rows, between 1 and 1e3 (tmpc_kernels.hip has the reasoning; the oracle starts alike)
+                double l1 = 0.0;
+                for (int r = tid; r < ncp; r += BT)
+                    if (valid_row(r)) l1 = fmax(l1, -s_[r] * bq.ci[r]);
+                l1 = block_reduce1<SH::BW, OpMax>(l1, red, wave, lane);
+                const double lam0 = fmin(fmax(sqrt(sqrt(l1)), 1.0), 1e3);
                 for (int r = tid; r < ncp; r += BT) {
                     const bool valid = valid_row(r);
                     s_[r] = valid ? fmax(s_[r], fl) : 1.0;
-                    lam_[r] = valid ? 1.0 : 0.0;
+                    lam_[r] = valid ? lam0 : 0.0;
                 }
             }
             double try_tol = qp.tol;

@@ -14,6 +14,12 @@
 
 namespace tmpc {
 
+// First two words of the files tmpc_debug_dump_layout / _block_layout write (include/tmpc.h): a tag and the version of the
+// record layout below -- bumped whenever DeviceQP / BlockQP or the list of dumped arrays changes, so that a reader built
+// against another layout (tests/wavesim) rejects the file instead of mis-parsing it.
+constexpr int32_t DUMP_TAG = 0x43504d54;       // "TMPC"
+constexpr int32_t DUMP_FORMAT = 3;             // 2: BlockQP with mir / ng / ngp, Grm = [ngp + NVP][NVP], 19th record Gw; 3: cip / ci (records 20 / 20)
+
 // Working set handed from one solve to the next (closed loop): per instance WS_STRIDE ints = [m, row ids ...]; a row id is
 // (row side) * 64 + lane in the wave kernel's slot layout.  m = 0: nothing to start from.
 constexpr int WS_CAP = 36;       // largest working set the refinement handles (24 for the shapes with NV <= 24)
@@ -39,6 +45,8 @@ struct DeviceQP {
     const double *F2s;    // [nv][nx]
     const double *g0p;    // [RS*64]       right-hand side offsets per row side, slot layout (padding: 1); RS = 2 DP + DS + 2 CP + CS
     const double *Esp;    // [nx][RS*64]   right-hand side dependence on x_k, slot layout, one plane per state (coalesced per lane)
+    const double *cip;    // [RS*64]       1 / (g Hs^-1 g') per row side, slot layout (padding: 0): the multiplier of the QP with that
+                          //               row alone is its violation times this (starting point of the interior-point phase)
     const uint32_t *vmask;   // [64]       bit i of entry l: row side i of lane l is a real row
     const int32_t *row_of;   // [RS*64]    row (order of Condensed::Gs) behind each row side, -1: padding
     const double *gp0;    // [npar]
@@ -75,6 +83,7 @@ struct BlockQP {
     const double *GHrm;   // [ncp][NVP]  G * Hs^-1 by constraint row, row-major (refinement: S = G_W Hs^-1 G_W')
     const double *g0;     // [ncp]       right-hand side offsets (padding rows: 1)
     const double *Es;     // [ncp][nx]   right-hand side dependence on x_k
+    const double *ci;     // [ncp]       1 / (g Hs^-1 g') per constraint row (padding rows: 0), see DeviceQP::cip
     const int32_t *ncols; // [ngp]       columns a row of G reaches (its zeros beyond are skipped); rows >= nz4 are ordered by it
     int row_start[9];     // row_start[t]: first row of G that reaches the 16-column tile t (row_start[0] = nz4; ng if none)
 };

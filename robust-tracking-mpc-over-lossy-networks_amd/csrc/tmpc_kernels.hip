@@ -156,15 +156,6 @@ __device__ __forceinline__ void wave_reduce_to_lds(const double (&acc)[CNT], dou
 template <int NV>
 __host__ __device__ constexpr int col_off(int j) { return j * NV - j * (j - 1) / 2; }
 
-// Column blocks of the lower triangle accumulated per pass over the dense functionals (<= ~55 accumulators each, the first
-// block also carries the NV entries of G'(d.r_p)).
-template <int NV> struct Blocks;
-template <> struct Blocks<8>  { static constexpr int n = 1; static constexpr int b[2] = {0, 8}; };
-template <> struct Blocks<12> { static constexpr int n = 4; static constexpr int b[5] = {0, 2, 4, 7, 12}; };
-template <> struct Blocks<16> { static constexpr int n = 4; static constexpr int b[5] = {0, 2, 5, 9, 16}; };
-template <> struct Blocks<24> { static constexpr int n = 8; static constexpr int b[9] = {0, 1, 3, 5, 7, 10, 13, 17, 24}; };
-template <> struct Blocks<28> { static constexpr int n = 10; static constexpr int b[11] = {0, 1, 3, 5, 7, 9, 11, 14, 17, 21, 28}; };
-
 // entries per round of the transposition tile: 12 where the LDS is short (two waves per SIMD; the NV = 28 shape), else 16
 constexpr int tile_rows(int nv, int wpb) { return (wpb == 8 || nv > 24) ? 12 : 16; }
 
@@ -178,12 +169,15 @@ struct Shape {
     static constexpr int RS = 2 * DP_ + DS_ + 2 * CP_ + CS_;      // row sides per lane
     static constexpr int NT = NV_ * (NV_ + 1) / 2, KT = KC_ * (KC_ + 1) / 2;
     static constexpr int WCAP = NV_ <= 24 ? 24 : 28;              // max rows in the refinement's working set (<= WS_CAP)
-    // row strides of the small LDS matrices that are read with the row on the lane (Hs, Hs^-1, the expanded working rows;
-    // T = Hs^-1 G_W'): odd, so that the lanes' rows start in different banks (NV = 24 unpadded: six rows per bank)
-    // (not for NV = 28: that shape's four workspaces fill the LDS to the last kilobyte, and padding Hs / Hs^-1 alone -- which
-    // would still fit at N = 20 -- measured no gain there)
-    static constexpr int LDH = NV_ + (NV_ <= 24 ? 1 : 0);                                         // Hs, Hs^-1
-    static constexpr int LDW = NV_ + (NV_ <= 24 ? 1 : 0), LDT = WCAP + (NV_ <= 24 ? 1 : 0);      // G_W, T
+    // Row strides of the small LDS matrices that are read with the row on the lane (Hs, Hs^-1, the normal matrix, the expanded
+    // working rows, T = Hs^-1 G_W'): ODD, so that the lanes' rows start in different banks (an even stride of 24 puts six rows
+    // on a bank, 28 four).  The variable count of a shape is the problem's own where that pays (NV = 11, 22, 26 for the
+    // cart-pole at N = 10 and N = 20 / 21): a round-3 shape of 12 / 24 / 28 variables did the work of the padding columns
+    // in every NV-long loop and NV^2 / 2 of it in the eliminations, and the 28-wide one had no LDS left for odd strides.
+    static constexpr int odd_up(int v) { return v | 1; }
+    static constexpr int LDH = odd_up(NV_);                       // Hs, Hs^-1
+    static constexpr int LDM = odd_up(NV_ + 1);                   // normal matrix / its factor: NV entries and 1 / d_i per row
+    static constexpr int LDW = odd_up(NV_), LDT = odd_up(WCAP);   // G_W, T
     // dense functionals, row-major in LDS: [FD * 64][LDG]; 16-column blocks of the MFMA tiling cover the NV columns of G
     // plus one more row of the product (row NV of A carries t: see sweep_a_dense); the odd stride keeps both the
     // lane-per-row reads of the sweeps and the 4 x 16 operand reads of the MFMA loop conflict free
@@ -214,7 +208,7 @@ template <class SH>
 struct WaveLds {
     static constexpr int RED = SH::RR * RED_STRIDE;                                     // transposition tile
     static constexpr int POL = SH::WCAP * SH::LDW + SH::NV * SH::LDT + 4 * SH::WCAP;              // G_W, T, y, dy, W(idx)
-    static constexpr int MFAC = SH::NV * (SH::NV + 1);                                  // factor of the normal matrix between the two solves (row i at i (NV + 1), then 1 / d_i)
+    static constexpr int MFAC = SH::NV * SH::LDM;                                       // factor of the normal matrix between the two solves (row i at i LDM, then 1 / d_i)
     static constexpr int BIG = RED + MFAC > POL ? RED + MFAC : POL;                     // tile + factor (interior point) and the refinement's workspace are never live together
     static constexpr int SUMS = 2 * SH::NV + 8;                                         // two NV-vectors of G' products
     static constexpr int CSUMS = SH::KT + 2 * SH::KC + 8;                               // factored-block totals
@@ -276,7 +270,7 @@ __device__ __forceinline__ double fact_dot(const double *Hct, const double *c, i
 // per-lane accumulators (NV (NV + 1) / 2 of them in a vector-ALU formulation) and no cross-lane reduction.  A operand
 // (16 x 4 per k-step): lane l holds column k = l / 16 of row i = l % 16, i.e. D_f g_f[16 I + i] of functional f = 4 ks + k
 // (row NV: t_f); B operand (4 x 16): g_f[16 J + j], j = l % 16 -- the same LDS value, read once.  C/D: lane l holds
-// rows (l / 16) + 4 reg, column l % 16 of a tile.  The tiles go to LDS as full rows of M (mt, stride NV + 1) and row NV
+// rows (l / 16) + 4 reg, column l % 16 of a tile.  The tiles go to LDS as full rows of M (mt, stride LDM) and row NV
 // as the vector G't (gdr).
 typedef double v4d __attribute__((ext_vector_type(4)));
 template <class SH>
@@ -350,7 +344,7 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, int nks, const d
         if (ks < nks) multiply(std::integral_constant<int, 0>{}, D0, t0, g0);
     }
     static_assert(WaveLds<SH>::RED >= 2 * (SH::NDP + 4), "look-ahead of the MFMA pass stays inside the transposition tile");
-    double *mtk = mt + kq * (NV + 1) + c;
+    double *mtk = mt + kq * SH::LDM + c;
 #pragma unroll
     for (int I = 0; I < NB; ++I)
 #pragma unroll
@@ -361,8 +355,8 @@ __device__ __forceinline__ void sweep_a_dense(const double *Gt, int nks, const d
                 double v = acc[0][I * (I + 1) / 2 + J][reg];
                 if constexpr (NACC == 2) v += acc[1][I * (I + 1) / 2 + J][reg];
                 if (row < NV && col < NV) {
-                    mtk[(16 * I + 4 * reg) * (NV + 1) + 16 * J] = v;
-                    if (I != J) mt[col * (NV + 1) + row] = v;
+                    mtk[(16 * I + 4 * reg) * SH::LDM + 16 * J] = v;
+                    if (I != J) mt[col * SH::LDM + row] = v;
                 }
                 if (I == IT && row == NV && col < NV) gdr[col] = v;
             }
@@ -450,7 +444,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *hw = Pm + WL::PMAT;                   // h, [side][lane]
     double *vec = hw + WL::HROW;
     double *dtw = red;                // [NDP][2] (D, t) of the dense functionals during the MFMA pass of sweep A (the tile is idle then)
-    double *Mf = red + WL::RED;       // [NV][NV + 1]  normal matrix, then its factor (behind the transposition tile, inside the refinement's idle workspace)
+    double *Mf = red + WL::RED;       // [NV][LDM]  normal matrix, then its factor (behind the transposition tile, inside the refinement's idle workspace)
     unsigned *park = reinterpret_cast<unsigned *>(red + WL::POL);   // [RS][64] parked (s, lambda), see WaveLds::PARK_LDS
     double *qv = vec;                 // [NV] linear term
     double *zv = vec + NV;            // [NV] current z (wave-uniform copy)
@@ -685,12 +679,27 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     const double smin = wave_min(raw_slacks(s));
                     const double fl = 0.1 * fmax(-smin, 1.0);
                     h_valid = false;
+                    // Starting multipliers.  The QP with row r ALONE has the multiplier viol_r / (g_r Hs^-1 g_r') at its
+                    // minimiser: the largest of them over the violated rows is the scale the multipliers have to reach (1e1 ...
+                    // 1e3 for the cart-pole, whose cost weights span seven decades), and the interior-point phase grows its
+                    // multipliers by a decade or so per iteration.  lambda_0 = (that scale)^(1/4), between 1 and 1e3 --
+                    // round 3 started from 1 whatever the problem: the iteration count falls by 3 - 7 % and its upper tail,
+                    // which sets the launch time of a batch, by more (the oracle and the block kernel alike).
+                    double l1 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < RS; ++i) l1 = vmax(l1, valid(i) ? -s[i] * qp.cip[i * WAVE + lane] : 0.0);
+                    l1 = wave_max(l1);
+#ifdef TMPC_LAM0_ONE
+                    const double lam0 = l1 < 0.0 ? 2.0 : 1.0;      // (diagnostic builds: the round-3 start)
+#else
+                    const double lam0 = fmin(fmax(sqrt(sqrt(l1)), 1.0), 1e3);
+#endif
 #pragma unroll
                     for (int i = 0; i < RS; ++i) {
                         const bool vl = valid(i);
                         const double raw = s[i];
                         s[i] = vl ? fmax(raw, fl) : 1.0;
-                        lam[i] = vl ? 1.0 : 0.0;
+                        lam[i] = vl ? lam0 : 0.0;
                         rpw[i * WAVE + lane] = vl ? s[i] - raw : 0.0;   // r_p = G z + s - h with h - G z = raw; carried from here on:
                         rs[i] = 1.0;                                    // the Newton step gives r_p <- (1 - alpha) r_p exactly (ds = -r_p - G dz)
                     }
@@ -843,9 +852,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                         double shift = 0.0;
                         bool spd = false;
                         for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
-                            // M = Hs + G'DG: the dense part sits in the tile (rows of stride NV + 1, written by the MFMA pass), the
+                            // M = Hs + G'DG: the dense part sits in the tile (rows of stride LDM, written by the MFMA pass), the
                             // factored part is Psi' (W Psi); the NV^2 entries are spread over the 64 lanes, then lane i reads row i
-                            double *mt = Mf + li * (NV + 1);        // (not the transposition tile: the dual-residual pass may have used it)
+                            double *mt = Mf + li * SH::LDM;        // (not the transposition tile: the dual-residual pass may have used it)
                             if (attempt == 0) {
 #pragma unroll
                                 for (int q = 0; q * WAVE < NV * NV; ++q) {
@@ -853,12 +862,12 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     if (e < NV * NV) {
                                         const int i = e / NV, j = e - i * NV;
                                         double v = Hs[i * SH::LDH + j];
-                                        if constexpr (FD > 0) v += Mf[i * (NV + 1) + j];
+                                        if constexpr (FD > 0) v += Mf[i * SH::LDM + j];
                                         if constexpr (KC > 0) {
 #pragma unroll
                                             for (int a = 0; a < KC; ++a) v += Psi[a * NV + i] * Pm[a * NV + j];
                                         }
-                                        Mf[i * (NV + 1) + j] = v;
+                                        Mf[i * SH::LDM + j] = v;
                                     }
                                 }
                             } else if (lane < NV) {
@@ -878,8 +887,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     dzav[lane] = xl;
                                     // the factor waits in LDS for the corrector's solve: 2 NV registers less through sweep B
 #pragma unroll
-                                    for (int j = 0; j < NV; ++j) Mf[li * (NV + 1) + j] = mrow[j];
-                                    Mf[li * (NV + 1) + NV] = mdinv;
+                                    for (int j = 0; j < NV; ++j) Mf[li * SH::LDM + j] = mrow[j];
+                                    Mf[li * SH::LDM + NV] = mdinv;
                                 }
                             } else {
                                 // non-positive pivot from cancellation: retry once with a 1e-13 * trace(M) shift (the rows of M are
@@ -980,8 +989,8 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     {
                         double mrow[NV];
 #pragma unroll
-                        for (int j = 0; j < NV; ++j) mrow[j] = Mf[li * (NV + 1) + j];
-                        const double mdinv = Mf[li * (NV + 1) + NV];
+                        for (int j = 0; j < NV; ++j) mrow[j] = Mf[li * SH::LDM + j];
+                        const double mdinv = Mf[li * SH::LDM + NV];
                         double bb = (lane < NV) ? rhs_i + v2 - smu * v3 : 0.0;
                         lanes_forward<NV>(mrow, bb, lane);
                         const double xl = lanes_backsub_lane<NV>(mrow, bb, mdinv, lane);
@@ -1539,17 +1548,17 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
 // N = 20; terminal block of 420 rows = 210 functionals of width 5), packet-received problem at N <= 11 and N <= 23
 // (initial-state block Z (-) W of 854 rows = 427 functionals of width 4).
 #if defined(TMPC_ONLY_BENCH)
-#define TMPC_SHAPES(X) X(12, 1, 0, 5, 4, 0)
+#define TMPC_SHAPES(X) X(11, 1, 0, 5, 4, 0)
 #elif defined(TMPC_SIM_SHAPES_N20)
 // tests/wavesim, developer builds: the two shapes of the cart-pole at the reference's horizon N = 20
-#define TMPC_SHAPES(X) X(24, 2, 0, 5, 4, 0) X(28, 2, 0, 4, 7, 0)
+#define TMPC_SHAPES(X) X(22, 2, 0, 5, 4, 0) X(26, 2, 0, 4, 7, 0)
 #elif defined(TMPC_SIM_SHAPES)
 // tests/wavesim: the bench shape (paired + factored functionals) and the shape of BASELINE config 1 (all rows dense and single)
-#define TMPC_SHAPES(X) X(12, 1, 0, 5, 4, 0) X(8, 0, 2, 0, 0, 0)
+#define TMPC_SHAPES(X) X(11, 1, 0, 5, 4, 0) X(8, 0, 2, 0, 0, 0)
 #else
 #define TMPC_SHAPES(X) \
     X(8, 0, 2, 0, 0, 0) X(8, 0, 4, 0, 0, 0) X(12, 0, 2, 0, 0, 0) X(12, 0, 4, 0, 0, 0) X(16, 0, 2, 0, 0, 0) X(16, 0, 4, 0, 0, 0) \
-    X(12, 1, 0, 5, 4, 0) X(24, 2, 0, 5, 4, 0) X(16, 1, 0, 4, 7, 0) X(28, 2, 0, 4, 7, 0)
+    X(11, 1, 0, 5, 4, 0) X(12, 1, 0, 5, 4, 0) X(22, 2, 0, 5, 4, 0) X(24, 2, 0, 5, 4, 0) X(15, 1, 0, 4, 7, 0) X(16, 1, 0, 4, 7, 0) X(26, 2, 0, 4, 7, 0)
 #endif
 
 size_t lds_bytes(const KernelShape &s, int grows) {

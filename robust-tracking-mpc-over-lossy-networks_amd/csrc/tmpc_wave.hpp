@@ -158,26 +158,97 @@ template <int N, class F>
 __device__ __forceinline__ void static_for_n(F &&f) {
     [&]<int... I>(std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }(std::make_integer_sequence<int, N>{});
 }
+// acc + (lane K of v's 16-lane row) * m in ONE instruction: v_fmac_f64 is a two-operand (VOP2) instruction on gfx90a and later
+// and takes the DPP operand itself (`v_fmac_f64_dpp dst, src0, src1 row_newbcast:K`: dst += dpp(src0) * src1).  The compiler
+// does not fuse a 64-bit DPP move into the multiply-add that consumes it (round 3 shipped v_mov_b64_dpp + v_fma_f64: two
+// instructions and one more link in every dependent chain of the eliminations), hence inline assembly.
+// Hazard (gfx9 family, software managed): a vector-ALU write of a VGPR needs two wait states before a DPP read of it, and the
+// compiler's hazard recognizer does not look into inline assembly.  The statements are `asm volatile`, i.e. they stay in
+// program order among themselves; NOPS > 0 puts `s_nop NOPS-1` in front where the DPP operand may have been written by the
+// statement just before (the dependent chains of the substitutions), and the callers order their statements so that the
+// other operands were written at least two instructions earlier (each routine says how).
+// (-DTMPC_NO_DPP_FMAC: diagnostic builds with the compiler's two-instruction form)
+template <int K, int NOPS>
+__device__ __forceinline__ void fmac_bcast(double &acc, double v, double m) {
+#if defined(TMPC_HOST_SIM) || defined(TMPC_NO_DPP_FMAC)
+    acc = fma(row_bcast_d<K>(v), m, acc);
+#else
+    if constexpr (NOPS > 0)
+        asm volatile("s_nop %3\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(acc) : "v"(v), "v"(m), "n"(NOPS - 1), "n"(K));
+    else
+        asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(m), "n"(K));
+#endif
+}
+// the pivot broadcast in the same (volatile) instruction order as the updates: `v` may have been written by the update two
+// statements back (last elimination steps), which the compiler cannot see
+template <int K, int NOPS>
+__device__ __forceinline__ double row_bcast_ordered(double v) {
+#if defined(TMPC_HOST_SIM) || defined(TMPC_NO_DPP_FMAC)
+    return row_bcast_d<K>(v);
+#else
+    double r;
+    if constexpr (NOPS > 0)
+        asm volatile("s_nop %2\n\tv_mov_b64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(NOPS - 1), "n"(K));
+    else
+        asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+#endif
+}
+// pins a value: everything that produces `v` is issued before the (empty, volatile) statement, which in turn stays in front
+// of the volatile statements that follow
+__device__ __forceinline__ void pin(double &v) {
+#if !defined(TMPC_HOST_SIM) && !defined(TMPC_NO_DPP_FMAC)
+    asm volatile("" : "+v"(v));
+#endif
+}
 // returns whether the matrix of lanes 0 .. N-1 had positive pivots (wave-uniform)
+// Software pipelined: the update of column k+1 comes FIRST in step k, the next pivot is broadcast two updates later (the two
+// wait states of the DPP read) and its reciprocal -- rcp and four dependent multiply-adds, the longest chain of a step -- runs
+// while the remaining updates of step k issue.  Order of the other DPP reads: an update of step k reads a register written in
+// step k-1, with at least the pivot broadcast and the multiplier's instructions in between.  The inputs of step 0 come from
+// LDS loads (guarded by s_waitcnt) and, b, from the caller through pin().
 template <int N>
 __device__ __forceinline__ bool rows16_factor(double (&row)[N], double &b, double &dinv, int lane) {
     static_assert(N <= 16, "one matrix row per lane of a 16-lane DPP row");
     const int l16 = lane & 15;
     bool ok = true;
+    pin(b);
+    double pkk = row_bcast_ordered<0, 0>(row[0]);
+    double pinv = fast_rcp(pkk);
     static_for_n<N>([&](auto k_) {
         constexpr int k = decltype(k_)::value;
-        const double pkk = row_bcast_d<k>(row[k]);
         ok = ok && (pkk > 0.0);
-        const double pinv = fast_rcp(pkk);
-        const double f = (l16 > k) ? row[k] * pinv : 0.0;
-#pragma unroll
-        for (int j = k + 1; j < N; ++j) row[j] = fma(-f, row_bcast_d<k>(row[j]), row[j]);
-        b = fma(-f, row_bcast_d<k>(b), b);
+        const double pinv_k = pinv;
+        const double f = (l16 > k) ? row[k] * pinv_k : 0.0;
+        const double nf = -f;
+        constexpr int NU = N - 1 - k;              // columns still to update
+        // columns k+1, k+2, k+3 (b takes a place when fewer are left), then the next pivot, then the rest
+        static_for_n<(NU < 3 ? NU : 3)>([&](auto j_) {
+            constexpr int j = k + 1 + decltype(j_)::value;
+            fmac_bcast<k, 0>(row[j], row[j], nf);
+        });
+        if constexpr (NU < 3) fmac_bcast<k, 0>(b, b, nf);
+        if constexpr (k + 1 < N) {
+            // (NU = 1: one update and b since the write of row[k+1]: two instructions; NU = 2: row[k+2] and b)
+            pkk = row_bcast_ordered<k + 1, 0>(row[k + 1]);
+            pinv = fast_rcp(pkk);
+        }
+        if constexpr (NU >= 3) {
+            static_for_n<NU - 3>([&](auto j_) {
+                constexpr int j = k + 4 + decltype(j_)::value;
+                fmac_bcast<k, 0>(row[j], row[j], nf);
+            });
+            fmac_bcast<k, 0>(b, b, nf);
+        }
         if (l16 > k) row[k] = f;
-        if (l16 == k) dinv = pinv;
+        if (l16 == k) dinv = pinv_k;
     });
     return __builtin_amdgcn_readfirstlane(static_cast<int>(ok)) != 0;
 }
+// The substitutions are ONE dependent chain on b -- every step reads through DPP what the step before wrote, which costs the
+// two wait states whatever the instruction --: the fused form gains nothing there, and the compiler fills the wait states of
+// its own two-instruction form (v_mov_b64_dpp + v_fma_f64) with the selects of the neighbouring steps.
 template <int N>
 __device__ __forceinline__ void rows16_forward(const double (&row)[N], double &b, int lane) {
     const int l16 = lane & 15;

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import common
 from LinearMPCOverNetworks import _native
+if os.environ.get('TMPC_LIB'):
+    _native.LIB_PATH = os.path.abspath(os.environ['TMPC_LIB'])
 mpc, w = common.make_mpc("cartpole", 20, True, extended=True, create=True)
 SX = common.harvest_states("cartpole", 20, True, [[0.5], [-0.4, 0.3], [0.2, -0.5, 0.1]], 60, seed=4, disturb=False, extended=True)
 rng = np.random.default_rng(0)

@@ -15,7 +15,7 @@ import common
 from LinearMPCOverNetworks import _native
 
 _BQ_INTS = ("ncp", "nz4", "zx0", "znx", "mir", "ng", "ngp")
-_ARRAYS = ("Hs", "Hinv", "F1s", "F2s", "gp0", "Ep", "Dv", "Tzs", "Txf", "Mth", "A", "B", "Grm", "Gcm", "GHrm", "g0", "Es", "ncols", "Gw")
+_ARRAYS = ("Hs", "Hinv", "F1s", "F2s", "gp0", "Ep", "Dv", "Tzs", "Txf", "Mth", "A", "B", "Grm", "Gcm", "GHrm", "g0", "Es", "ncols", "Gw", "ci")
 
 
 def _layout(h, tmp_path):
@@ -24,9 +24,11 @@ def _layout(h, tmp_path):
     L.tmpc_debug_dump_block_layout.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
     assert L.tmpc_debug_dump_block_layout(h.ptr, 0, path.encode()) == 0
     raw = open(path, "rb").read()
-    tiles, ws_rows = struct.unpack_from("ii", raw, 0)
-    sz_d, sz_bq = struct.unpack_from("QQ", raw, 8)
-    off = 24 + sz_d
+    tag, fmt = struct.unpack_from("ii", raw, 0)
+    assert tag == 0x43504D54 and fmt == 3, (hex(tag), fmt)      # "TMPC", tmpc::DUMP_FORMAT (csrc/tmpc_device.hpp): the record list below
+    tiles, ws_rows = struct.unpack_from("ii", raw, 8)
+    sz_d, sz_bq = struct.unpack_from("QQ", raw, 16)
+    off = 32 + sz_d
     bq = dict(zip(_BQ_INTS, struct.unpack_from("7i", raw, off)))
     off += sz_bq
     arrs = {}

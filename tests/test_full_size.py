@@ -18,7 +18,7 @@ OUT = os.path.join(os.path.dirname(common.PKG), "gpurun_out")
 
 def test_config3_extended_gamma_mix_at_65536(hip_lib, oracle_lib):
     """Cart-pole N = 20 (results_linear_system.py:64), ExtendedTubeTrackingMPC: (x_hat, ref, gamma) of extended closed loops
-    (what bench.py's config3 solves), both problems in one call: solve_kernel<24,2,0,5,4,0> and solve_kernel<28,2,0,4,7,0>."""
+    (what bench.py's config3 solves), both problems in one call: solve_kernel<22,2,0,5,4,0> and solve_kernel<26,2,0,4,7,0>."""
     from LinearMPCOverNetworks import workloads
     mpc, w = workloads.make_controller("cartpole", 20, True, extended=True, device=0)
     assert mpc.get_kernel_path(0) == "wave" and mpc.get_kernel_path(1) == "wave"

@@ -279,7 +279,7 @@ def test_extended_controller_both_problems(hip_lib, oracle_lib, N):
     mpc, _ = common.make_mpc("cartpole", N, True, extended=True, create=True)
     nv1, nc1, _ = hip_lib.get_dims(mpc._handle, 1)
     assert nv1 == N + 1 + 4 and nc1 > 900 and mpc.get_kernel_path(1) == "wave"
-    assert hip_lib.kernel_name(mpc._handle, 1).startswith("tmpc::solve_kernel<%d,%d,0,4,7,0," % ((16, 1) if N == 10 else (28, 2)))
+    assert hip_lib.kernel_name(mpc._handle, 1).startswith("tmpc::solve_kernel<%d,%d,0,4,7,0," % ((15, 1) if N == 10 else (26, 2)))      # the shape of exactly nv = N + 5 variables
     SX = common.harvest_states("cartpole", N, True, [[0.5], [-0.4, 0.3], [0.2, -0.5, 0.1]], 40, seed=4, disturb=True, extended=True)
     gam = np.random.default_rng(1).integers(0, 2, len(SX)).astype(np.uint8)
     ref = Oracle(mpc._problem_dict()).solve(SX[:, :4], SX[:, 4:], gam)

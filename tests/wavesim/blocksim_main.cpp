@@ -23,6 +23,8 @@ int main(int argc, char **argv) {
     uint64_t sz[2];
     tmpc::DeviceQP d;
     tmpc::BlockQP bq;
+    int32_t tag[2];
+    need(std::fread(tag, 4, 2, f) == 2 && tag[0] == tmpc::DUMP_TAG && tag[1] == tmpc::DUMP_FORMAT, "layout file of another dump format");
     need(std::fread(hd, 4, 2, f) == 2 && std::fread(sz, 8, 2, f) == 2, "short layout file");
     need(sz[0] == sizeof d && sz[1] == sizeof bq && hd[1] == tmpc::block_workspace_rows(), "layout file written for other structures");
     need(std::fread(&d, sizeof d, 1, f) == 1 && std::fread(&bq, sizeof bq, 1, f) == 1, "short layout file");
@@ -32,7 +34,7 @@ int main(int argc, char **argv) {
                              reinterpret_cast<const void **>(&d.Mth), reinterpret_cast<const void **>(&d.A), reinterpret_cast<const void **>(&d.B),
                              reinterpret_cast<const void **>(&bq.Grm), reinterpret_cast<const void **>(&bq.Gcm), reinterpret_cast<const void **>(&bq.GHrm),
                              reinterpret_cast<const void **>(&bq.g0), reinterpret_cast<const void **>(&bq.Es), reinterpret_cast<const void **>(&bq.ncols),
-                             reinterpret_cast<const void **>(&bq.Gw)};
+                             reinterpret_cast<const void **>(&bq.Gw), reinterpret_cast<const void **>(&bq.ci)};
     std::vector<std::unique_ptr<char[]>> keep;
     for (const void **fp : fields) {
         uint64_t n;
@@ -45,7 +47,7 @@ int main(int argc, char **argv) {
     std::fclose(f);
     if (bq.Gw == nullptr) bq.Gw = bq.Grm;          // a row of G per constraint row (BlockQP::mir == 0)
     d.dbg = nullptr; d.save = nullptr; d.ticks = nullptr;
-    d.Gt = d.Hct = d.Psi = d.g0p = d.Esp = nullptr; d.vmask = nullptr; d.row_of = nullptr;
+    d.Gt = d.Hct = d.Psi = d.g0p = d.Esp = d.cip = nullptr; d.vmask = nullptr; d.row_of = nullptr;
 
     f = std::fopen(argv[2], "rb");
     need(f != nullptr, "cannot open batch file");

@@ -31,6 +31,8 @@ void read_layout(const char *path, Layout &L) {
     need(f != nullptr, "cannot open layout file");
     int32_t shp[6];
     uint64_t qb;
+    int32_t tag[2];
+    need(std::fread(tag, 4, 2, f) == 2 && tag[0] == tmpc::DUMP_TAG && tag[1] == tmpc::DUMP_FORMAT, "layout file of another dump format");
     need(std::fread(shp, 4, 6, f) == 6 && std::fread(&qb, 8, 1, f) == 1, "short layout file");
     need(qb == sizeof(tmpc::DeviceQP), "layout file written for another DeviceQP");
     need(std::fread(&L.d, sizeof L.d, 1, f) == 1, "short layout file");
@@ -44,7 +46,7 @@ void read_layout(const char *path, Layout &L) {
                              reinterpret_cast<const void **>(&L.d.Ep), reinterpret_cast<const void **>(&L.d.Dv),
                              reinterpret_cast<const void **>(&L.d.Tzs), reinterpret_cast<const void **>(&L.d.Txf),
                              reinterpret_cast<const void **>(&L.d.Mth), reinterpret_cast<const void **>(&L.d.A),
-                             reinterpret_cast<const void **>(&L.d.B)};
+                             reinterpret_cast<const void **>(&L.d.B), reinterpret_cast<const void **>(&L.d.cip)};
     for (const void **fp : fields) {
         uint64_t n;
         need(std::fread(&n, 8, 1, f) == 1, "short layout file");
