@@ -7,20 +7,26 @@
 // shortcut, Mehrotra predictor-corrector interior point on the normal equations, active-set
 // refinement by proximal Newton steps), different mapping to the machine:
 //
-//   * one workgroup of 256 threads (4 waves) per QP instance, persistent, grid-stride over the batch;
-//   * the per-row state (s, lambda, r_p, d, ...) lives in a per-workgroup workspace in HBM/L2, laid
-//     out [quantity][row]: thread t owns rows t, t+256, ...; every access is a coalesced stream and
-//     the register footprint does not depend on the number of rows, so several workgroups share a CU;
+//   * one workgroup per QP instance: 256 threads (4 waves, two workgroups per CU) up to 64 variables, 512 threads (8 waves = two per
+//     SIMD, one workgroup per CU) for 65 .. 128; persistent workgroups, the first instance of each is its index in the grid, the
+//     later ones are drawn from the launch's work counter;
+//   * the per-row state (s, lambda, h, G z and four arrays shared by the quantities of an iteration: enum WS_* below) lives in a
+//     per-workgroup workspace slice in HBM/L2, laid out [quantity][row]: thread t owns rows t, t + BT, ...; every access is a
+//     coalesced stream and the register footprint does not depend on the number of rows;
+//   * when every constraint row has its mirror row (box-type sets: all of BASELINE's models) a row of G is a FUNCTIONAL serving
+//     both sides (BlockQP::mir): the three G-sized passes of an iteration read half the rows;
 //   * M = Hs + G'DG -- nc*nv^2 of the ~nc*nv^2 + nv^3/3 flops of an iteration -- is formed with
 //     v_mfma_f64_16x16x4_f64: A = (d .* G)' and B = G are read straight from the row-major copy of G
 //     (one f64 per lane and k-step, 4 x 128 B segments per load), the 16x16 tiles of the lower
-//     triangle are spread over the four waves (tile rows g and T-1-g per group; for small nv the
-//     waves also split the rows and add their partial tiles in LDS);
-//   * M is factored in LDS by the whole workgroup (right-looking Cholesky), the triangular solves
-//     run in wave 0 with the right-hand side held one/two entries per lane (v_readlane broadcast);
-//   * G'v products (two vectors per pass) use thread-per-(column, row part) over the row-major
-//     copy; G v products thread-per-row over the column-major copy; G z itself is carried along
-//     incrementally (G z += alpha G dz).
+//     triangle are dealt to the waves as tile rows g and T-1-g, the structural zeros of the condensed rows (stage k acts on
+//     u_0 .. u_k only) are skipped by tile (BlockQP::row_start); for small nv the waves also split the rows and add their
+//     partial tiles in LDS;
+//   * M is factored in LDS by the whole workgroup (blocked right-looking Cholesky: 16 x 16 diagonal blocks in the registers of
+//     wave 0, panel by thread per row, trailing update on the matrix cores), L^-1 is formed explicitly (W' in the upper
+//     triangle of the same LDS matrix) and the two solves of an iteration are four matrix-vector products by all threads;
+//   * G'v products (two vectors per pass) use thread-per-(column pair, row part) over the row-major
+//     copy, with Hs z riding along in the pass of the dual residual; G v products thread-per-row-pair over the column-major
+//     copy; G z itself is carried along incrementally (G z += alpha G dz).
 #ifdef TMPC_HOST_SIM
 #include "hip_sim.hpp"      // tests/wavesim: this very source compiled for the CPU under sanitizers (never in the product)
 #else
@@ -92,7 +98,18 @@ constexpr int block_threads(int tiles) { return tiles >= 8 ? 512 : 256; }
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // rows of the per-workgroup workspace, each [ncp] doubles
-enum { WS_S, WS_LAM, WS_H, WS_GZ, WS_RP, WS_D, WS_V1, WS_W, WS_C1, WS_RS, WS_DS, WS_DL, WS_GDZ, WS_Y, WS_RR, WS_INW, WS_COUNT };
+// Per-row state of a workgroup in its workspace slice: EIGHT arrays of ncp doubles.  Round 3 kept sixteen (164 KB per workgroup for
+// config 5: 32 workgroups of an XCD and the two copies of G overflowed its 4 MB L2, and every pass wrote its arrays through to
+// HBM -- 9.4 GB per launch of 16384 instances).  Quantities whose lifetimes within an iteration do not overlap share an array;
+// each hand-over is a read and a write of the SAME row by the SAME thread (the statement order in p5_row / p7_row):
+//   WS_D   d = lambda / s (P1 .. P5)           then w = ds_aff * dl_aff (P5 .. P7)
+//   WS_V1  d * r_p (P1 .. P2)                  then w / s (P5 .. P6)            then dl (P7 .. P8)
+//   WS_RS  1 / s (P5 .. P7)                    then ds (P7 .. P8)
+//   WS_RP  r_p (P1 .. P7)                      then G dz (P7 .. P8)
+// and the refinement's arrays (multipliers, row residuals, membership flags) take the places of r_p, d and d * r_p, which the
+// interior-point phase forms anew (P1) when it continues after a refinement that did not certify.
+enum { WS_S, WS_LAM, WS_H, WS_GZ, WS_RP, WS_D, WS_V1, WS_RS, WS_COUNT,
+       WS_W = WS_D, WS_C1 = WS_V1, WS_DL = WS_V1, WS_DS = WS_RS, WS_GDZ = WS_RP, WS_Y = WS_RP, WS_RR = WS_D, WS_INW = WS_V1 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -861,7 +878,7 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
         }
     };
 
-    // the sixteen workspace arrays are offsets of W0, formed where they are used (sixteen live pointers before)
+    // the workspace arrays are offsets of W0, formed where they are used (sixteen live pointers in round 2)
     double *W0 = lp->ws + static_cast<size_t>(blockIdx.x) * WS_COUNT * ncp;
 #define WSP(k) (W0 + static_cast<size_t>(k) * ncp)
 #define s_ WSP(WS_S)

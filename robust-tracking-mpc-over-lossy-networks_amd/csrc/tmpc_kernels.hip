@@ -81,6 +81,9 @@ constexpr int ZERO_ROWS = 4;        // zero rows behind the staged dense functio
 #define STAMP(p) do { asm volatile("; MARK " #p); } while (0)
 #endif
 
+#ifndef TMPC_FENCE_ALL
+#define TMPC_FENCE_ALL 0      // diagnostic builds: 1 keeps the barrier in the one-wave-per-SIMD shapes as well
+#endif
 // Compiler-only barrier between two slots of a sweep: without it the loads of ALL slots are hoisted to the top of the
 // unrolled loop and the kernel spills to scratch.
 #ifdef TMPC_HOST_SIM
@@ -369,7 +372,7 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
                                                  const double *rpw, double (&rs)[SH::RS], double &gap_l, double &rpn_l,
                                                  double *red, double *csums, int lane) {
     constexpr int KC = SH::KC, KT = SH::KT, NCCP = SH::NCCP;
-    double acc[KT + KC];       // initialised by the first slot's products
+    double acc[KT + KC + 1];   // initialised by the first slot's products; the last entry carries the wave's complementarity gap
     static_for<SH::FC>([&](auto kc_) {
         constexpr int kc = decltype(kc_)::value;
         const int r = lane + kc * WAVE;
@@ -398,7 +401,10 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
             acc[KT + a] = kc == 0 ? hc[a] * t : fma(hc[a], t, acc[KT + a]);
         }
     });
-    wave_reduce_to_lds<KT + KC, SH::RR>(acc, red, csums, lane);
+    // (the gap of ALL row sides of the lane rides along: a free place of the second round instead of a wave reduction of its
+    // own -- eight DPP moves, eight v_readlane and a dependent chain of a hundred and fifty cycles)
+    acc[KT + KC] = gap_l;
+    wave_reduce_to_lds<KT + KC + 1, SH::RR>(acc, red, csums, lane);
 }
 
 template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
@@ -526,14 +532,30 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
             TMPC_REFRESH();
             // h = g0 + E x_k: one plane of E per state, the RS loads of a plane are issued together (nx round trips to L2
             // instead of RS nx: this runs at set-up and again at every hand-over, its LDS region holds r_p in between)
+            // (four planes at a time, all of their loads in flight together with those of g0: a round trip to L2 costs some 2000
+            // cycles here, and plane by plane -- round 3 -- the cart-pole's h took five of them: 11 k cycles per call, at the
+            // set-up and again at every hand-over, 3 % of an instance)
             double hv[RS];
+            const double *__restrict__ E0 = qp.Esp + lane;
+            constexpr size_t PL = static_cast<size_t>(RS) * WAVE;
+            for (int c0 = 0; c0 < nx; c0 += 4) {
+                double ev[4][RS];
 #pragma unroll
-            for (int i = 0; i < RS; ++i) hv[i] = qp.g0p[i * WAVE + lane];
-            for (int c = 0; c < nx; ++c) {
-                const double xc = xin[c];
-                const double *__restrict__ Ec = qp.Esp + static_cast<size_t>(c) * (RS * WAVE) + lane;
+                for (int u = 0; u < 4; ++u) {
+                    const size_t cu = static_cast<size_t>(c0 + u < nx ? c0 + u : nx - 1);      // (planes beyond nx: a valid address, weight 0)
 #pragma unroll
-                for (int i = 0; i < RS; ++i) hv[i] = fma(Ec[i * WAVE], xc, hv[i]);
+                    for (int i = 0; i < RS; ++i) ev[u][i] = E0[cu * PL + i * WAVE];
+                }
+                if (c0 == 0) {
+#pragma unroll
+                    for (int i = 0; i < RS; ++i) hv[i] = qp.g0p[i * WAVE + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double xc = c0 + u < nx ? xin[c0 + u] : 0.0;
+#pragma unroll
+                    for (int i = 0; i < RS; ++i) hv[i] = fma(ev[u][i], xc, hv[i]);
+                }
             }
             double hmax = 1.0;
 #pragma unroll
@@ -742,7 +764,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     for (int i = 0; i < RS; ++i) lmax_l = vmax(lmax_l, lam[i]);
                     const bool rp_small = !__any(rpn_l > try_tol * hn);
                     const bool lam_big = __any(lmax_l > 1e10);
-                    const double gap = wave_sum(gap_l);
+                    double gap;
+                    if constexpr (KC > 0) gap = readlane_d(csums[KT + KC], 0);       // (summed with the factored block's totals: sweep_a_factored)
+                    else gap = wave_sum(gap_l);
                     const double mu = gap / ncd;
                     STAMP(1);
                     TMPC_REFRESH();
@@ -778,7 +802,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 if constexpr (SH::dsides(kd) == 2) dl2 -= lam[SH::dbase(kd) + 1];
 #pragma unroll
                                 for (int j = 0; j < NV; ++j) accl[j] = fma(Gt[r * LDG + j], dl2, accl[j]);
-                                row_fence();
+                                if constexpr (WPB == 8 || TMPC_FENCE_ALL) row_fence();
                             });
                             wave_reduce_to_lds<NV, SH::RR>(accl, red, sums + NV, lane);
                         }
@@ -944,12 +968,12 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     accb[j] = kd == 0 ? g[j] * c1 : fma(g[j], c1, accb[j]);
                                     accb[NV + j] = kd == 0 ? g[j] * c2 : fma(g[j], c2, accb[NV + j]);
                                 }
-                                row_fence();
+                                if constexpr (WPB == 8 || TMPC_FENCE_ALL) row_fence();
                             });
                             wave_reduce_to_lds<2 * NV, SH::RR>(accb, red, sums, lane);   // overwrites G'(d.rp), G'lam (consumed)
                         }
                         if constexpr (KC > 0) {
-                            double accc[2 * KC];
+                            double accc[2 * KC + 2];       // (+ the two sums of the affine step's statistics: see sweep_a_factored)
                             static_for<FC>([&](auto kc_) {
                                 constexpr int kc = decltype(kc_)::value;
                                 const int r = lane + kc * WAVE;
@@ -966,11 +990,16 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     accc[KC + a] = kc == 0 ? hc[a] * c2 : fma(hc[a], c2, accc[KC + a]);
                                 }
                             });
-                            wave_reduce_to_lds<2 * KC, SH::RR>(accc, red, csums + KT, lane);
+                            accc[2 * KC] = sb1;
+                            accc[2 * KC + 1] = sb2;
+                            wave_reduce_to_lds<2 * KC + 2, SH::RR>(accc, red, csums + KT, lane);
+                            sb1 = readlane_d(csums[KT + 2 * KC], 0);
+                            sb2 = readlane_d(csums[KT + 2 * KC + 1], 0);
+                        } else {
+                            sb1 = wave_sum(sb1);
+                            sb2 = wave_sum(sb2);
                         }
                         rho_aff = wave_max(rho_aff);
-                        sb1 = wave_sum(sb1);
-                        sb2 = wave_sum(sb2);
                         if (lane < NV) {
                             if constexpr (FD > 0) { v2 = sums[lane]; v3 = sums[NV + lane]; }
                             if constexpr (KC > 0) {
@@ -1022,7 +1051,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                             const double gdz = dense_dot<SH, kd>(Gt, grows, dzv, lane);
 #pragma unroll
                             for (int sd = 0; sd < SH::dsides(kd); ++sd) side_step(SH::dbase(kd) + sd, sd == 1, gdz);
-                            row_fence();
+                            if constexpr (WPB == 8 || TMPC_FENCE_ALL) row_fence();
                         });
                         static_for<FC>([&](auto kc_) {
                             constexpr int kc = decltype(kc_)::value;
