@@ -898,10 +898,18 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                 mt[li] += shift;
                             }
                             wave_lds_fence();
+                            rhs_i = (lane < NV) ? -cgv[li] - sums[li] : 0.0;
+                            if constexpr (NV > wv::DPP_ROW && wv::DPP_ROW > 0) {
+                                // two matrix rows per lane, DPP forms throughout (tmpc_wave.hpp: rows32_*); the right-hand side goes
+                                // through LDS, the factor stays in place of the matrix
+                                if (lane < NV) tv[lane] = rhs_i;
+                                wave_lds_fence();
+                                spd = wv::rows32_factor_solve<NV, SH::LDM>(Mf, tv, dzav, lane);
+                                (void)mrow; (void)mdinv;
+                            } else {
 #pragma unroll
                             for (int j = 0; j < NV; ++j) mrow[j] = mt[j];      // (lanes >= NV eliminate a copy of row 0 that nothing reads)
                             wave_lds_fence();
-                            rhs_i = (lane < NV) ? -cgv[li] - sums[li] : 0.0;
                             double bb = rhs_i;
                             mdinv = 1.0;
                             spd = lanes_factor<NV>(mrow, bb, mdinv, lane);
@@ -914,6 +922,9 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                                     for (int j = 0; j < NV; ++j) Mf[li * SH::LDM + j] = mrow[j];
                                     Mf[li * SH::LDM + NV] = mdinv;
                                 }
+                            }
+                            }
+                            if (spd) {
                             } else {
                                 // non-positive pivot from cancellation: retry once with a 1e-13 * trace(M) shift (the rows of M are
                                 // still in the tile)
@@ -1015,7 +1026,11 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
                     double sigma = mu_aff / mu;
                     sigma = fmin(sigma * sigma * sigma, 1.0);
                     const double smu = sigma * mu;
-                    {
+                    if constexpr (NV > wv::DPP_ROW && wv::DPP_ROW > 0) {
+                        if (lane < NV) tv[lane] = rhs_i + v2 - smu * v3;
+                        wave_lds_fence();
+                        wv::rows32_resolve<NV, SH::LDM>(Mf, tv, dzv, lane);
+                    } else {
                         double mrow[NV];
 #pragma unroll
                         for (int j = 0; j < NV; ++j) mrow[j] = Mf[li * SH::LDM + j];

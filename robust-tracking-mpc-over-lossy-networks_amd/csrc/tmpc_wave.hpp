@@ -271,6 +271,150 @@ __device__ __forceinline__ double rows16_backsub_lane(const double (&row)[N], do
     });
     return xl;
 }
+// ---- 16 < N <= 32: TWO matrix rows per lane -- lane i of every 16-lane row holds rows i (`ra`) and i + 16 (`rb`) -- so that every
+// pivot row sits on a lane of the SAME 16-lane row as the rows it updates and the DPP forms above apply: an update is one
+// v_fmac_f64_dpp per row half (two per column while the pivot is among the first sixteen rows, one afterwards) where the
+// one-row-per-lane form of round 3 needed two v_readlane_b32 and a multiply-add with a scalar operand, i.e. a scalar-register
+// round trip in every link of every chain (N = 26: 1 053 instructions for the elimination against 605 fused updates).
+// The matrix lives in LDS (rows of stride LDM: N entries, then 1 / d_i) before and after: `rows32_factor_solve` reads the rows,
+// eliminates with the right-hand side `rhs` (LDS, [N]) carried along, leaves the factor in place of the matrix and the solution
+// in `x` (LDS, [N]); `rows32_resolve` solves with the stored factor.  Lanes whose second row does not exist (i + 16 >= N) carry
+// a copy of row 0 with multipliers forced to zero.
+template <int N, int LDM>
+__device__ __forceinline__ bool rows32_factor_solve(double *Mf, const double *rhs, double *x, int lane) {
+    static_assert(N > 16 && N <= 32, "two matrix rows per lane");
+    const int l16 = lane & 15;
+    const bool hasb = l16 + 16 < N;
+    const int ib = hasb ? l16 + 16 : 0;
+    double ra[N], rb[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { ra[j] = Mf[l16 * LDM + j]; rb[j] = Mf[ib * LDM + j]; }
+    double ba = rhs[l16], bb = hasb ? rhs[ib] : 0.0;
+    double da = 1.0, db = 1.0;
+    lds_fence();
+    bool ok = true;
+    pin(ba);
+    pin(bb);
+    static_for_n<N>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        constexpr bool inA = k < 16;
+        constexpr int kl = k & 15;
+        // (the pivot entry was written by the first updates of step k - 1; only the last steps have fewer than two statements behind it)
+        double pkk;
+        if constexpr (inA) pkk = row_bcast_ordered<kl, (k >= N - 2 ? 2 : 0)>(ra[k]);
+        else pkk = row_bcast_ordered<kl, (k >= N - 2 ? 2 : 0)>(rb[k]);
+        ok = ok && (pkk > 0.0);
+        const double pinv = fast_rcp(pkk);
+        double nfa = 0.0;
+        if constexpr (inA) nfa = (l16 > k) ? -ra[k] * pinv : 0.0;
+        const double nfb = (hasb && l16 + 16 > k) ? -rb[k] * pinv : 0.0;
+        static_for_n<N - 1 - k>([&](auto j_) {
+            constexpr int j = k + 1 + decltype(j_)::value;
+            // (the lower half first: it reads the pivot row's entry of `ra` before the upper half's own update writes that register)
+            if constexpr (inA) {
+                fmac_bcast<kl, 0>(rb[j], ra[j], nfb);
+                fmac_bcast<kl, 0>(ra[j], ra[j], nfa);
+            } else {
+                fmac_bcast<kl, 0>(rb[j], rb[j], nfb);
+            }
+        });
+        if constexpr (inA) {
+            fmac_bcast<kl, 0>(bb, ba, nfb);
+            fmac_bcast<kl, 0>(ba, ba, nfa);
+            if (l16 > k) ra[k] = -nfa;
+            if (l16 == k) da = pinv;
+        } else {
+            fmac_bcast<kl, 0>(bb, bb, nfb);
+            if (l16 == kl) db = pinv;
+        }
+        if (hasb && l16 + 16 > k) rb[k] = -nfb;
+    });
+    ok = __builtin_amdgcn_readfirstlane(static_cast<int>(ok)) != 0;
+    if (!ok) return false;
+    // back substitution (compiler's DPP form: one dependent chain, see rows16_backsub_lane); x_i ends on lane i & 15
+    double xa = 0.0, xb = 0.0;
+    static_for_n<N>([&](auto r_) {
+        constexpr int i = N - 1 - decltype(r_)::value;
+        constexpr int il = i & 15;
+        if constexpr (i >= 16) {
+            const double bi = bb * db;
+            const double xi = row_bcast_d<il>(bi);
+            xb = (l16 == il) ? bi : xb;
+            bb = fma(-rb[i], xi, bb);
+            ba = fma(-ra[i], xi, ba);
+        } else {
+            const double bi = ba * da;
+            const double xi = row_bcast_d<il>(bi);
+            xa = (l16 == il) ? bi : xa;
+            ba = fma(-ra[i], xi, ba);
+        }
+    });
+    if (lane < 16) {
+        x[l16] = xa;
+        if (hasb) x[ib] = xb;
+        // the factor waits in LDS for the corrector's solve
+#pragma unroll
+        for (int j = 0; j < N; ++j) Mf[l16 * LDM + j] = ra[j];
+        Mf[l16 * LDM + N] = da;
+        if (hasb) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) Mf[ib * LDM + j] = rb[j];
+            Mf[ib * LDM + N] = db;
+        }
+    }
+    lds_fence();
+    return true;
+}
+template <int N, int LDM>
+__device__ __forceinline__ void rows32_resolve(const double *Mf, const double *rhs, double *x, int lane) {
+    const int l16 = lane & 15;
+    const bool hasb = l16 + 16 < N;
+    const int ib = hasb ? l16 + 16 : 0;
+    double ra[N], rb[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) { ra[j] = Mf[l16 * LDM + j]; rb[j] = Mf[ib * LDM + j]; }
+    const double da = Mf[l16 * LDM + N], db = Mf[ib * LDM + N];
+    double ba = rhs[l16], bb = hasb ? rhs[ib] : 0.0;
+    lds_fence();
+    // forward substitution with the stored multipliers
+    static_for_n<N - 1>([&](auto k_) {
+        constexpr int k = decltype(k_)::value;
+        constexpr int kl = k & 15;
+        const double fb = (hasb && l16 + 16 > k) ? rb[k] : 0.0;
+        if constexpr (k < 16) {
+            const double fa = (l16 > k) ? ra[k] : 0.0;
+            const double xk = row_bcast_d<kl>(ba);
+            ba = fma(-fa, xk, ba);
+            bb = fma(-fb, xk, bb);
+        } else {
+            const double xk = row_bcast_d<kl>(bb);
+            bb = fma(-fb, xk, bb);
+        }
+    });
+    double xa = 0.0, xb = 0.0;
+    static_for_n<N>([&](auto r_) {
+        constexpr int i = N - 1 - decltype(r_)::value;
+        constexpr int il = i & 15;
+        if constexpr (i >= 16) {
+            const double bi = bb * db;
+            const double xi = row_bcast_d<il>(bi);
+            xb = (l16 == il) ? bi : xb;
+            bb = fma(-rb[i], xi, bb);
+            ba = fma(-ra[i], xi, ba);
+        } else {
+            const double bi = ba * da;
+            const double xi = row_bcast_d<il>(bi);
+            xa = (l16 == il) ? bi : xa;
+            ba = fma(-ra[i], xi, ba);
+        }
+    });
+    if (lane < 16) {
+        x[l16] = xa;
+        if (hasb) x[ib] = xb;
+    }
+    lds_fence();
+}
+
 // dispatch: the DPP form where a matrix fits a 16-lane row, the readlane form otherwise (-DTMPC_NO_DPP64: diagnostic
 // builds with the readlane form throughout)
 #ifdef TMPC_NO_DPP64
