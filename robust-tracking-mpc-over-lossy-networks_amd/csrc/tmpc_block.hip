@@ -293,12 +293,24 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
             v2d g[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) g[k] = (r + k * PARTS >= rs) ? G2[static_cast<size_t>(r + k * PARTS) * NV2] : zero2;
-#pragma unroll
-            for (int k = 0; k < 16; k += 2) {
-                const double xa0 = readlane_d(xal, k), xb0 = readlane_d(xbl, k), xa1 = readlane_d(xal, k + 1), xb1 = readlane_d(xbl, k + 1);
-                a0 += g[k] * xa0; b0 += g[k] * xb0;
-                a1 += g[k + 1] * xa1; b1 += g[k + 1] * xb1;
-            }
+            // (the weight of row k is lane k's of every 16-lane row: the DPP operand of the multiply-add itself, wv::fmac_bcast --
+            // round 3 brought it to scalar registers with two v_readlane_b32 per weight first: 8 instead of 4 instructions per row)
+            double xad = xal, xbd = xbl;
+            wv::pin(xad);
+            wv::pin(xbd);
+            double a0x = a0.x, a0y = a0.y, b0x = b0.x, b0y = b0.y, a1x = a1.x, a1y = a1.y, b1x = b1.x, b1y = b1.y;
+            wv::static_for_n<8>([&](auto k2_) {
+                constexpr int k = 2 * decltype(k2_)::value;
+                wv::fmac_bcast<k, (k == 0 ? 2 : 0)>(a0x, xad, g[k].x);
+                wv::fmac_bcast<k, (k == 0 ? 2 : 0)>(b0x, xbd, g[k].x);
+                wv::fmac_bcast<k, 0>(a0y, xad, g[k].y);
+                wv::fmac_bcast<k, 0>(b0y, xbd, g[k].y);
+                wv::fmac_bcast<k + 1, 0>(a1x, xad, g[k + 1].x);
+                wv::fmac_bcast<k + 1, 0>(b1x, xbd, g[k + 1].x);
+                wv::fmac_bcast<k + 1, 0>(a1y, xad, g[k + 1].y);
+                wv::fmac_bcast<k + 1, 0>(b1y, xbd, g[k + 1].y);
+            });
+            a0 = v2d{a0x, a0y}; b0 = v2d{b0x, b0y}; a1 = v2d{a1x, a1y}; b1 = v2d{b1x, b1y};
         }
     } else {
         for (; r + 7 * PARTS < nc; r += 8 * PARTS) {           // several row parts per wave: eight rows in flight, weights per lane
@@ -573,8 +585,12 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
 #pragma unroll
             for (int k = 0; k < 16; ++k) a[k] = (li < nl && k <= li) ? Mx[(c0 + li) * ld + c0 + k] : (k == li ? 1.0 : 0.0);
             bool good = true;
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
+            // Column j of L scaled, then a[k] -= a[j] * (a[j] of lane k) for k > j: the broadcast of lane k's entry is the DPP
+            // operand of the multiply-add itself (v_fmac_f64_dpp ... row_newbcast:k, wv::fmac_bcast) -- round 3 fetched it with two
+            // v_readlane_b32 into scalar registers first: three instructions and a scalar round trip per update of a chain that the
+            // other seven waves of the workgroup wait for.  (The first update of a step follows the write of a[j]: two wait states.)
+            wv::static_for_n<16>([&](auto j_) {
+                constexpr int j = decltype(j_)::value;
                 double pj = readlane_d(a[j], j);
                 if (!(pj > 0.0)) { good = false; pj = 1.0; }
                 double inv = __builtin_amdgcn_rsq(pj);        // 1 / sqrt(p_j): v_rsq_f64 + three Newton steps
@@ -582,12 +598,14 @@ __device__ __forceinline__ bool block_chol(double *Mx, int ld, int n, double *di
                 for (int nr = 0; nr < 3; ++nr) inv = fma(0.5 * inv, fma(-pj * inv, inv, 1.0), inv);
                 a[j] *= inv;
                 if (lane == 0 && j < nl) dinv[c0 + j] = inv;
-#pragma unroll
-                for (int k = j + 1; k < 16; ++k) {
-                    const double lkj = readlane_d(a[j], k);
-                    a[k] = fma(-a[j], lkj, a[k]);
-                }
-            }
+                double naj = -a[j];
+                wv::pin(naj);          // (a[j] and its negative are in place before the updates, which stay in this order)
+                wv::static_for_n<15 - j>([&](auto k_) {
+                    constexpr int k = j + 1 + decltype(k_)::value;
+                    if constexpr (k == j + 1) wv::fmac_bcast<k, 2>(a[k], a[j], naj);
+                    else wv::fmac_bcast<k, 0>(a[k], a[j], naj);
+                });
+            });
             if (lane < nl) {
 #pragma unroll
                 for (int k = 0; k < 15; ++k)
