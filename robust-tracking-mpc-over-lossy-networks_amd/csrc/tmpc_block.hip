@@ -411,7 +411,7 @@ __device__ __noinline__ void gt_products(const double *__restrict__ Grm, int nc,
 // the tiles of row RA alone and [ksB, nsteps) for both rows.
 template <int T, int RA, int RB>
 __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const double *__restrict__ dvec, int ksA, int ksB, int nsteps,
-                                          int rpart, double *M, int lane, int mir) {
+                                          int rpart, double *M, int lane, int mir, const double *__restrict__ Hsg, double shift) {
     using SH = BShape<T>;
     constexpr int NVP = SH::NVP, LDM = SH::LDM, RS = SH::RSPLIT;
     constexpr int NA = RA + 1, NB = RB + 1;
@@ -471,8 +471,38 @@ __device__ __forceinline__ void gdg_group(const double *__restrict__ Grm, const 
     if constexpr (NA > 0) pass(std::false_type{}, ksA, ksB);
     pass(std::true_type{}, ksB, nsteps);
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // The first row part of a tile row WRITES M = Hs + (shift on the diagonal) + its tiles, the others add theirs: the entries of Hs come
+    // straight from L2 with all of a lane's loads in flight (round 3 copied the whole NVP x NVP matrix into LDS first, a phase of
+    // its own between two barriers: 6 % of an instance).  Only the lower tile triangle is written: nothing reads M above it before
+    // the inverse puts W' there.
+    if (rpart == 0) {
+        double hB[NB][4], hA[NAA][4];
 #pragma unroll
-    for (int p = 0; p < RS; ++p) {
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) hB[t][reg] = Hsg[(16 * RB + kq + 4 * reg) * NVP + 16 * t + c];
+        if constexpr (NA > 0) {
+#pragma unroll
+            for (int t = 0; t < NA; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) hA[t][reg] = Hsg[(16 * RA + kq + 4 * reg) * NVP + 16 * t + c];
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg)
+                M[(16 * RB + kq + 4 * reg) * LDM + 16 * t + c] = hB[t][reg] + accB[t][reg] + ((t == RB && kq + 4 * reg == c) ? shift : 0.0);
+        if constexpr (NA > 0) {
+#pragma unroll
+            for (int t = 0; t < NA; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    M[(16 * RA + kq + 4 * reg) * LDM + 16 * t + c] = hA[t][reg] + accA[t][reg] + ((t == RA && kq + 4 * reg == c) ? shift : 0.0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 1; p < RS; ++p) {
         if (rpart == p) {
 #pragma unroll
             for (int t = 0; t < NB; ++t)
@@ -534,23 +564,23 @@ __device__ __forceinline__ void zblock_accumulate(const double *__restrict__ Grm
 
 template <int T>
 __device__ __forceinline__ void gdg_all(const double *__restrict__ Grm, const double *__restrict__ dvec, CBlockQP &bq, int nsteps,
-                                        double *M, int wave, int lane) {
+                                        double *M, int wave, int lane, const double *__restrict__ Hsg, double shift) {
     constexpr int G = BShape<T>::G;
     const int g = wave % G, rpart = wave / G;
     const int ks0 = bq.nz4 / 4;                    // k-steps below belong to the initial-state rows (handled apart)
     const int mir = bq.mir;
     auto first = [&](int t) { const int k = bq.row_start[t] / 4; return k > ks0 ? k : ks0; };
     if constexpr (G == 1) {
-        if constexpr (T == 1) gdg_group<T, -1, 0>(Grm, dvec, ks0, ks0, nsteps, rpart, M, lane, mir);
-        else gdg_group<T, 0, 1>(Grm, dvec, first(0), first(1), nsteps, rpart, M, lane, mir);
+        if constexpr (T == 1) gdg_group<T, -1, 0>(Grm, dvec, ks0, ks0, nsteps, rpart, M, lane, mir, Hsg, shift);
+        else gdg_group<T, 0, 1>(Grm, dvec, first(0), first(1), nsteps, rpart, M, lane, mir, Hsg, shift);
     } else if constexpr (G == 2) {
-        if (g == 0) gdg_group<T, 0, 3>(Grm, dvec, first(0), first(3), nsteps, rpart, M, lane, mir);
-        else gdg_group<T, 1, 2>(Grm, dvec, first(1), first(2), nsteps, rpart, M, lane, mir);
+        if (g == 0) gdg_group<T, 0, 3>(Grm, dvec, first(0), first(3), nsteps, rpart, M, lane, mir, Hsg, shift);
+        else gdg_group<T, 1, 2>(Grm, dvec, first(1), first(2), nsteps, rpart, M, lane, mir, Hsg, shift);
     } else {
-        if (g == 0) gdg_group<T, 0, 7>(Grm, dvec, first(0), first(7), nsteps, rpart, M, lane, mir);
-        else if (g == 1) gdg_group<T, 1, 6>(Grm, dvec, first(1), first(6), nsteps, rpart, M, lane, mir);
-        else if (g == 2) gdg_group<T, 2, 5>(Grm, dvec, first(2), first(5), nsteps, rpart, M, lane, mir);
-        else gdg_group<T, 3, 4>(Grm, dvec, first(3), first(4), nsteps, rpart, M, lane, mir);
+        if (g == 0) gdg_group<T, 0, 7>(Grm, dvec, first(0), first(7), nsteps, rpart, M, lane, mir, Hsg, shift);
+        else if (g == 1) gdg_group<T, 1, 6>(Grm, dvec, first(1), first(6), nsteps, rpart, M, lane, mir, Hsg, shift);
+        else if (g == 2) gdg_group<T, 2, 5>(Grm, dvec, first(2), first(5), nsteps, rpart, M, lane, mir, Hsg, shift);
+        else gdg_group<T, 3, 4>(Grm, dvec, first(3), first(4), nsteps, rpart, M, lane, mir, Hsg, shift);
     }
 }
 
@@ -1080,26 +1110,9 @@ __global__ __launch_bounds__(BShape<T>::BT, BShape<T>::OCC) void solve_block_ker
                     double shift = 0.0;
                     bool spd = false;
                     for (int attempt = 0; attempt < 2 && !spd; ++attempt) {
-                        __syncthreads();
-                        {
-                            // (eight loads in flight: one at a time the copy was 32 dependent L2 round trips per thread)
-                            const double *__restrict__ Hsg = qp.Hs;
-                            constexpr int PER = NVP * NVP / BT, CH = PER >= 8 ? 8 : PER;
-                            static_assert(NVP * NVP % BT == 0 && PER % CH == 0, "Hs copy: whole trips");
-                            for (int c8 = 0; c8 < PER; c8 += CH) {
-                                double hv[CH];
-#pragma unroll
-                                for (int u = 0; u < CH; ++u) hv[u] = Hsg[tid + (c8 + u) * BT];
-#pragma unroll
-                                for (int u = 0; u < CH; ++u) {
-                                    const int idx = tid + (c8 + u) * BT, i = idx / NVP, j = idx - i * NVP;
-                                    big[i * LDM + j] = hv[u] + (i == j ? shift : 0.0);
-                                }
-                            }
-                        }
-                        __syncthreads();
+                        __syncthreads();           // (the previous readers of the LDS matrix are done)
                         BSTAMP(3);
-                        gdg_all<T>(Grm, d_, bq, nsteps, big, wave, lane);
+                        gdg_all<T>(Grm, d_, bq, nsteps, big, wave, lane, qp.Hs, shift);
                         zblock_accumulate<T>(Grm, d_, bq, big, parts, tid);
                         BSTAMP(4);
 #ifdef TMPC_STAMPS
