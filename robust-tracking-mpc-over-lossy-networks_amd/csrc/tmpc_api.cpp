@@ -63,8 +63,13 @@ struct tmpc_handle {
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
     int blk_ncp = 0;
     double *blk_ws = nullptr;
-    // staging buffers for the host-pointer entry point
+    // staging buffers for the host-pointer entry point: ONE device block, inputs [x | ref | variant] then outputs
+    // [u | x0 | ss | status | iters | x_nom], and a pinned host mirror of it -- a call moves its inputs with one DMA and its
+    // outputs with one (round 3: nine hipMemcpyAsync from / to pageable memory per call, 60 % of the time of a call at batch 1)
     int64_t cap = 0;
+    char *stage_dev = nullptr, *stage_pin = nullptr;
+    size_t stage_in_bytes = 0, stage_out_bytes = 0, stage_out_core = 0;      // (core = the outputs without x_nom)
+    size_t off_r = 0, off_var = 0, off_x0 = 0, off_ss = 0, off_st = 0, off_it = 0, off_xn = 0;      // offsets within the input / output parts
     double *d_x = nullptr, *d_r = nullptr, *d_u = nullptr, *d_x0 = nullptr, *d_ss = nullptr, *d_xn = nullptr;
     uint8_t *d_var = nullptr;
     int32_t *d_st = nullptr, *d_it = nullptr;
@@ -432,27 +437,63 @@ bool use_block(const tmpc_handle *h, const Variant &v) {
 }
 
 void free_staging(tmpc_handle *h) {
-    void *ptrs[] = {h->d_x, h->d_r, h->d_u, h->d_x0, h->d_ss, h->d_xn, h->d_var, h->d_st, h->d_it};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (h->stage_dev) (void)hipFree(h->stage_dev);
+    if (h->stage_pin) (void)hipHostFree(h->stage_pin);
+    h->stage_dev = h->stage_pin = nullptr;
     h->d_x = h->d_r = h->d_u = h->d_x0 = h->d_ss = h->d_xn = nullptr;
     h->d_var = nullptr; h->d_st = h->d_it = nullptr;
     h->cap = 0;
 }
 
-int ensure_staging(tmpc_handle *h, int64_t B) {
-    if (B <= h->cap) return TMPC_OK;
-    free_staging(h);
+// offsets and sub-buffers for a batch of B (tightly packed for THIS batch, whatever the capacity: the DMAs of a call move
+// exactly its bytes); returns the total
+size_t layout_staging(tmpc_handle *h, int64_t B) {
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B);
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_x), b * nx * sizeof(double)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_r), b * nx * sizeof(double)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_u), b * N * nu * sizeof(double)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_x0), b * nx * sizeof(double)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_ss), b * (nx + nu) * sizeof(double)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_xn), b * (N + 1) * nx * sizeof(double)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_var), b));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_st), b * sizeof(int32_t)));
-    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_it), b * sizeof(int32_t)));
-    h->cap = B;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    // inputs
+    h->off_r = up(b * nx * sizeof(double));
+    h->off_var = h->off_r + up(b * nx * sizeof(double));
+    h->stage_in_bytes = h->off_var + up(b);
+    // outputs (x_nom last: it is optional and by far the largest)
+    h->off_x0 = up(b * N * nu * sizeof(double));
+    h->off_ss = h->off_x0 + up(b * nx * sizeof(double));
+    h->off_st = h->off_ss + up(b * (nx + nu) * sizeof(double));
+    h->off_it = h->off_st + up(b * sizeof(int32_t));
+    h->stage_out_core = h->off_it + up(b * sizeof(int32_t));
+    h->off_xn = h->stage_out_core;
+    h->stage_out_bytes = h->off_xn + up(b * (N + 1) * nx * sizeof(double));
+    if (h->stage_dev != nullptr) {
+        char *in = h->stage_dev, *out = h->stage_dev + h->stage_in_bytes;
+        h->d_x = reinterpret_cast<double *>(in);
+        h->d_r = reinterpret_cast<double *>(in + h->off_r);
+        h->d_var = reinterpret_cast<uint8_t *>(in + h->off_var);
+        h->d_u = reinterpret_cast<double *>(out);
+        h->d_x0 = reinterpret_cast<double *>(out + h->off_x0);
+        h->d_ss = reinterpret_cast<double *>(out + h->off_ss);
+        h->d_st = reinterpret_cast<int32_t *>(out + h->off_st);
+        h->d_it = reinterpret_cast<int32_t *>(out + h->off_it);
+        h->d_xn = reinterpret_cast<double *>(out + h->off_xn);
+    }
+    return h->stage_in_bytes + h->stage_out_bytes;
+}
+
+int ensure_staging(tmpc_handle *h, int64_t B) {
+    if (B > h->cap) {
+        if (h->stream) HIP_TRY(h, hipStreamSynchronize(h->stream));
+        free_staging(h);
+        const size_t total = layout_staging(h, B);
+        HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->stage_dev), total));
+        // the pinned mirror is a convenience, not a requirement: without it (or beyond 64 MB) the call copies from / to the
+        // caller's buffers directly
+        if (total <= (64u << 20)) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&h->stage_pin), total, hipHostMallocDefault) != hipSuccess) {
+                h->stage_pin = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+        h->cap = B;
+    }
+    (void)layout_staging(h, B);
     return TMPC_OK;
 }
 
@@ -677,6 +718,28 @@ int tmpc_solve_batch(tmpc_handle *h, int64_t B, const double *x_k, const double 
     int rc = ensure_staging(h, B);
     if (rc) return rc;
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B);
+    if (h->stage_pin != nullptr) {
+        // through the pinned mirror: one DMA in, one out
+        char *pin_in = h->stage_pin, *pin_out = h->stage_pin + h->stage_in_bytes;
+        std::memcpy(pin_in, x_k, b * nx * sizeof(double));
+        std::memcpy(pin_in + h->off_r, ref, b * nx * sizeof(double));
+        size_t in_bytes = h->off_r + b * nx * sizeof(double);
+        if (variant) { std::memcpy(pin_in + h->off_var, variant, b); in_bytes = h->off_var + b; }
+        HIP_TRY(h, hipMemcpyAsync(h->stage_dev, pin_in, in_bytes, hipMemcpyHostToDevice, h->stream));
+        rc = enqueue(h, B, h->d_x, h->d_r, variant ? h->d_var : nullptr, h->d_u, h->d_x0, h->d_ss, x_nom ? h->d_xn : nullptr,
+                     h->d_st, h->d_it);
+        if (rc) return rc;
+        const size_t out_bytes = x_nom ? h->off_xn + b * (N + 1) * nx * sizeof(double) : h->off_it + b * sizeof(int32_t);
+        HIP_TRY(h, hipMemcpyAsync(pin_out, h->stage_dev + h->stage_in_bytes, out_bytes, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(h, hipStreamSynchronize(h->stream));
+        std::memcpy(u_nom, pin_out, b * N * nu * sizeof(double));
+        if (x_nom0) std::memcpy(x_nom0, pin_out + h->off_x0, b * nx * sizeof(double));
+        if (xu_ss) std::memcpy(xu_ss, pin_out + h->off_ss, b * (nx + nu) * sizeof(double));
+        std::memcpy(status, pin_out + h->off_st, b * sizeof(int32_t));
+        std::memcpy(iters, pin_out + h->off_it, b * sizeof(int32_t));
+        if (x_nom) std::memcpy(x_nom, pin_out + h->off_xn, b * (N + 1) * nx * sizeof(double));
+        return TMPC_OK;
+    }
     HIP_TRY(h, hipMemcpyAsync(h->d_x, x_k, b * nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIP_TRY(h, hipMemcpyAsync(h->d_r, ref, b * nx * sizeof(double), hipMemcpyHostToDevice, h->stream));
     if (variant) HIP_TRY(h, hipMemcpyAsync(h->d_var, variant, b, hipMemcpyHostToDevice, h->stream));
