@@ -97,3 +97,26 @@ def test_bench_refuses_more_nccl_ranks_than_gpus():
     if torch.cuda.device_count() >= 2:
         pytest.skip("this box has two GPUs")
     assert res.returncode == 3 and "RCCL needs one GPU per rank" in res.stderr, res.stderr[-2000:]
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    """The N > 1 path of bench.py with TWO ranks, as the driver launches it (torch.distributed.run, one process per rank), on the
+    one GPU a test box has: TMPC_BENCH_BACKEND=gloo lets the ranks share the device (RCCL wants a GPU per rank; the nccl branch is
+    covered by the single-rank tests above).  What it checks is the part the driver's scaling record depends on: both ranks join,
+    the line says so (`ranks_seen`, `per_rank_ms` with two entries), the value is the whole job's."""
+    env = dict(os.environ, TMPC_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                      # rank 0 prints the one line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    pr = line["per_rank_ms"]
+    assert pr["backend"] == "gloo" and len(pr["ms_per_step"]) == 2 and len(pr["avg_kernel_ms"]) == 2
+    assert abs(line["ms_per_step"] - max(pr["ms_per_step"])) < 0.05 * line["ms_per_step"] + 0.05      # the slowest rank's region (up to the barrier)
+    assert line["config"]["batch_per_gpu"] == 4096 and line["config"]["optimal_fraction"] == 1.0
+    assert abs(line["value"] - 2 * 4096 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-6 * line["value"]        # whole-job solves per second
