@@ -230,8 +230,9 @@ __device__ __forceinline__ bool rows16_factor(double (&row)[N], double &b, doubl
         });
         if constexpr (NU < 3) fmac_bcast<k, 0>(b, b, nf);
         if constexpr (k + 1 < N) {
-            // (NU = 1: one update and b since the write of row[k+1]: two instructions; NU = 2: row[k+2] and b)
-            pkk = row_bcast_ordered<k + 1, 0>(row[k + 1]);
+            // (two statements lie between the write of row[k+1] and this read of it -- the DPP hazard's two wait states -- except
+            // in the last step but one, where only the update of b does: NU = 1 waits)
+            pkk = row_bcast_ordered<k + 1, (NU == 1 ? 2 : 0)>(row[k + 1]);
             pinv = fast_rcp(pkk);
         }
         if constexpr (NU >= 3) {
