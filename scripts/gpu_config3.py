@@ -7,6 +7,8 @@ from LinearMPCOverNetworks import _native
 if os.environ.get('TMPC_LIB'):
     _native.LIB_PATH = os.path.abspath(os.environ['TMPC_LIB'])
 mpc, w = common.make_mpc("cartpole", 20, True, extended=True, create=True)
+if len(sys.argv) > 1:
+    mpc.set_kernel_path(sys.argv[1])          # "wave" / "block": developer knob, both problems through that kernel
 SX = common.harvest_states("cartpole", 20, True, [[0.5], [-0.4, 0.3], [0.2, -0.5, 0.1]], 60, seed=4, disturb=False, extended=True)
 rng = np.random.default_rng(0)
 B = 65536
