@@ -26,7 +26,7 @@ Metric: QP solves per second (= MPC steps per second), whole job.  The same JSON
                 the wall time of one determine_packet call, in ms) for 1000 calls at batch 1 through tmpc_solve_batch, host
                 pointers, copies included -- and for the CPU oracle on one thread;
   closed_loop_small   the reference's own experiment size (results_linear_system.py:64,147-149: N = 20, 10 loss rates x 20
-                runs x 250 steps) through the device-resident loop, wall seconds;
+                runs x 250 steps) through the device-resident loop, wall seconds (one fused launch, and a launch pair per step);
   ranks_seen / per_rank_ms   (multi-GPU) an all-reduce of ones and every rank's own timed region and average kernel time.
 Order of a one-GPU run: set-up, one solve + the statistics gather (loads torch's kernels), the extras, THEN the W warm-up steps and
 the K timed steps.  The first torch kernel of a process costs tens of milliseconds of host time; placed between the warm-up steps and
@@ -330,16 +330,27 @@ def main():
             mpc.run_closed_loop(pl[:64], ref_cl, th[:64], ga[:64], wd[:64])          # warm-up
             cl_out = {}
             for warm in (False, True):
-                tcl = time.perf_counter()
-                cl = mpc.run_closed_loop(pl, ref_cl, th, ga, wd, warm_start=warm)
-                tcl = time.perf_counter() - tcl
-                cl_out["warm" if warm else "cold"] = {
-                    "value": B * Tcl / tcl, "unit": "MPC steps/s", "tube_violations": int(cl["tube_violations"].sum()),
-                    "non_optimal_solves": int(cl["not_optimal"].sum()), "mean_ipm_iters": float(cl["iters_mean"]),
-                    "tracking_error_mean": float(cl["tracking_error"].mean())}
+                leg = {}
+                for mode in ("off", None):        # a launch pair per step, then the library's own choice (tmpc_mc_set_fused: AUTO)
+                    tcl = time.perf_counter()
+                    cl = mpc.run_closed_loop(pl, ref_cl, th, ga, wd, warm_start=warm, fused=mode)
+                    tcl = time.perf_counter() - tcl
+                    if mode == "off":
+                        leg["per_step_launches"] = {"value": B * Tcl / tcl, "launches": 2 * Tcl}
+                        ref_run = cl
+                        continue
+                    leg.update({"value": B * Tcl / tcl, "unit": "MPC steps/s", "fused": bool(cl["fused"]), "launches": 1 if cl["fused"] else 2 * Tcl,
+                                "same_as_per_step_bit_for_bit": bool(all(np.array_equal(cl[k], ref_run[k], equal_nan=True) for k in
+                                                                         ("err2", "x_final", "tube_violations", "not_optimal", "iters_sum"))),
+                                "tube_violations": int(cl["tube_violations"].sum()),
+                                "non_optimal_solves": int(cl["not_optimal"].sum()), "mean_ipm_iters": float(cl["iters_mean"]),
+                                "tracking_error_mean": float(cl["tracking_error"].mean())})
+                cl_out["warm" if warm else "cold"] = leg
             ex["closed_loop"] = {"trajectories": B, "steps": Tcl, "p_loss": 0.3, **cl_out,
-                                  "note": "end to end incl. upload of the realisations and download of the statistics; warm = every "
-                                          "solve first tries the working set of the trajectory's previous step in the exact refinement"}
+                                  "note": "end to end incl. upload of the realisations and download of the statistics; `value`: tmpc_mc_run as the "
+                                          "library runs it by default -- ONE launch for the sweep, a wavefront keeps its trajectory for all steps "
+                                          "(closed_loop_kernel) --, per_step_launches: one solve launch + one state-machine launch per step; warm = "
+                                          "every solve first tries the working set of the trajectory's previous step in the exact refinement"}
         if world == 1 and not args.no_extras:
             # The reference's own performance self-description (results_linear_system.py:305-315): wall time of ONE
             # determine_packet call, max / quantiles / median / mean in ms.  Here: 1000 calls at batch 1 through tmpc_solve_batch
@@ -365,15 +376,23 @@ def main():
             mpc20.run_closed_loop(pl20[:8], ref20[:20], th20[:8, :20], ga20[:8, :20], wd20[:8, :20])          # warm-up
             small = {}
             for warm in (False, True):
-                ts = time.perf_counter()
-                cl = mpc20.run_closed_loop(pl20, ref20, th20, ga20, wd20, warm_start=warm)
-                ts = time.perf_counter() - ts
-                small["warm" if warm else "cold"] = {"wall_s": ts, "ms_per_step": ts / 250 * 1e3, "MPC_steps_per_s": len(pl20) * 250 / ts,
-                                                     "tube_violations": int(cl["tube_violations"].sum()),
-                                                     "non_optimal_solves": int(cl["not_optimal"].sum())}
-            ex["closed_loop_small"] = {"trajectories": len(pl20), "steps": 250, "N": 20, "launches_per_step": 2, **small,
+                leg = {}
+                for mode in ("off", None):
+                    ts = time.perf_counter()
+                    cl = mpc20.run_closed_loop(pl20, ref20, th20, ga20, wd20, warm_start=warm, fused=mode)
+                    ts = time.perf_counter() - ts
+                    if mode == "off":
+                        leg["per_step_launches"] = {"wall_s": ts, "ms_per_step": ts / 250 * 1e3, "launches": 500}
+                        continue
+                    leg.update({"wall_s": ts, "ms_per_step": ts / 250 * 1e3, "MPC_steps_per_s": len(pl20) * 250 / ts, "fused": bool(cl["fused"]),
+                                "launches": 1 if cl["fused"] else 500, "tube_violations": int(cl["tube_violations"].sum()),
+                                "non_optimal_solves": int(cl["not_optimal"].sum())})
+                small["warm" if warm else "cold"] = leg
+            ex["closed_loop_small"] = {"trajectories": len(pl20), "steps": 250, "N": 20, **small,
                                        "note": "10 loss rates x 20 runs x 250 steps, N = 20 (results_linear_system.py:64,147-149), "
-                                               "tmpc_mc_run: one solve launch + one state-machine launch per step"}
+                                               "tmpc_mc_run: one launch for the whole experiment (200 wavefronts, each with its trajectory for 250 "
+                                               "steps: the figure is 250 x the latency of one solve + state machines); per_step_launches: a solve "
+                                               "launch + a state-machine launch per step"}
             del mpc20
             # offline stage extra: support-function LPs over this workload's terminal set in one launch (tmpc_lp_batch)
             Xf = mpc._Xf

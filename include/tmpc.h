@@ -267,6 +267,24 @@ int tmpc_mc_replay(tmpc_handle *h, int64_t B, int32_t T, int extended, const dou
 int tmpc_mc_set_warm_start(tmpc_handle *h, int on);
 
 /*
+ * How tmpc_mc_run steps its trajectories.  TMPC_MC_FUSED_ON: ONE launch for the whole sweep -- a wavefront keeps its
+ * trajectory for all T time steps and alternates between the QP solve and the trajectory's state machines inside the
+ * kernel (the reference's loop body, Results/results_linear_system.py:209-259, with nothing between two of its
+ * iterations).  TMPC_MC_FUSED_OFF: per time step one solve launch (per problem variant) and one
+ * launch of the state machines.  The two give the same numbers bit for bit: a trajectory's arithmetic does not depend on
+ * which wavefront runs it or when.  TMPC_MC_FUSED_AUTO (default): fused when the trajectories fill their rounds on the
+ * card's resident wavefronts to at least 85 % (or fit in one round), else per step -- a fused work item is T solves
+ * long, a per-step one a single solve.  Fusing needs ONE problem on the one-wave-per-QP kernel: the extended controller
+ * (two problems, chosen per step by the arrival flag), the workgroup-per-QP kernel and tmpc_mc_replay always step per
+ * launch.  tmpc_mc_last_fused: 1 if the last tmpc_mc_run of the handle ran fused.
+ */
+#define TMPC_MC_FUSED_OFF 0
+#define TMPC_MC_FUSED_ON 1
+#define TMPC_MC_FUSED_AUTO 2
+int tmpc_mc_set_fused(tmpc_handle *h, int mode);
+int tmpc_mc_last_fused(const tmpc_handle *h);
+
+/*
  * Per-solve computation times -- what the reference's controllers keep in _computational_times and the scripts print as
  * max / quantiles / median (TubeTrackingMPC.py:205, 242-243; results_linear_system.py:305-315).  On the device an MPC solve
  * is one instance of a batched launch; with tmpc_set_solve_timing(on) every instance records the time from the moment its

@@ -214,10 +214,12 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         return np.ascontiguousarray(U.transpose(0, 2, 1)), out["x_nom0"], out["status"]
 
     def run_closed_loop(self, p_loss, ref, th_u=None, ga_u=None, w=None, x0=None, extended: bool = False, plant=None,
-                        warm_start: bool = False, capture=None, timing: bool = False, device_rng=None) -> dict:
+                        warm_start: bool = False, capture=None, timing: bool = False, device_rng=None, fused=None) -> dict:
         """The lossy-network closed loop of the reference's Monte-Carlo scripts (results_linear_system.py:209-291)
-        for a batch of trajectories, resident on the device (include/tmpc.h: tmpc_mc_run): every time step is one
-        solve launch plus one state-machine launch, nothing returns to the host in between.  warm_start: every solve first
+        for a batch of trajectories, resident on the device (include/tmpc.h: tmpc_mc_run): ONE launch for the whole sweep
+        where the controller has one QP (a wavefront keeps its trajectory for all T steps: solve, state machines, solve, ...;
+        fused = "on" / "off" / "auto", tmpc_mc_set_fused; out["fused"] says what ran), else one solve launch per problem
+        plus one state-machine launch per time step; nothing returns to the host in between.  warm_start: every solve first
         tries the working set of the trajectory's previous solve in the exact refinement (same results, fewer iterations);
         capture: index of one trajectory whose x_t / x_nom_t / u_t are returned (the scripts' sample run, :298-301).
         timing: per trajectory the mean / maximum device time of a solve (solve_time_mean, solve_time_max, seconds); the
@@ -231,7 +233,7 @@ class TubeTrackingMPC(TubeRegulatorMPC):
         _native.mc_set_actuator(self._handle, self._smart_actuator)
         out = _native.mc_run(self._handle, p_loss, ref, th_u, ga_u, w, x0=x0, Z=None if self._smart_actuator else self._Z,
                              extended=extended, warm_start=warm_start, capture=capture, timing=timing,
-                             physics_substeps=0 if plant in (None, "linear") else 10, device_rng=device_rng)
+                             physics_substeps=0 if plant in (None, "linear") else 10, device_rng=device_rng, fused=fused)
         if timing:
             self._computational_times.extend(out["solve_time_mean"].tolist())
         return out

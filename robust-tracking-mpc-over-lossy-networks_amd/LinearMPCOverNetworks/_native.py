@@ -105,6 +105,10 @@ def lib():
         L.tmpc_mc_get_physics_error.restype = C.c_int
         L.tmpc_mc_set_warm_start.argtypes = [C.c_void_p, C.c_int]
         L.tmpc_mc_set_warm_start.restype = C.c_int
+        L.tmpc_mc_set_fused.argtypes = [C.c_void_p, C.c_int]
+        L.tmpc_mc_set_fused.restype = C.c_int
+        L.tmpc_mc_last_fused.argtypes = [C.c_void_p]
+        L.tmpc_mc_last_fused.restype = C.c_int
         L.tmpc_mc_run.restype = C.c_int
         L.tmpc_mc_replay.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int] + [C.c_void_p] * 8
         L.tmpc_mc_replay.restype = C.c_int
@@ -326,8 +330,11 @@ def mc_set_plant(h: Handle, plant=None, Th: float = 0.02, substeps: int = 10):
         raise RuntimeError(h.error())
 
 
+MC_FUSED = {"off": 0, "on": 1, "auto": 2, False: 0, True: 1, None: 2}      # include/tmpc.h: TMPC_MC_FUSED_*
+
+
 def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: bool = False, warm_start: bool = False,
-           capture=None, timing: bool = False, physics_substeps: int = 0, device_rng=None) -> dict:
+           capture=None, timing: bool = False, physics_substeps: int = 0, device_rng=None, fused=None) -> dict:
     """include/tmpc.h: tmpc_mc_run -- the closed loop over the lossy network, resident on the device.
     warm_start: tmpc_mc_set_warm_start for this call; capture: index of a trajectory to record (tmpc_mc_set_capture) ->
     x_traj (T, nx), x_nom_traj (T, nx), u_traj (T, nu) in the result; timing: per trajectory the mean and the maximum
@@ -336,8 +343,12 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
     over the physics-rate trajectory (tmpc_mc_get_physics_error, results_nonlinear_system.py:361).
     device_rng = (seed, first_trajectory, w_bound): the realisations are drawn on the device (tmpc_mc_set_device_rng;
     montecarlo.draw_realisations_philox gives the same numbers on the host); th_u, ga_u, w are then ignored and may be None,
-    the batch is len(p_loss) x len(ref)."""
+    the batch is len(p_loss) x len(ref).
+    fused: "on" / "off" / "auto" (None) -- tmpc_mc_set_fused: one launch for all T steps, a launch pair per step, or the library's
+    choice; the result's "fused" says what ran."""
     if lib().tmpc_set_solve_timing(h.ptr, int(bool(timing))) != 0:
+        raise RuntimeError(h.error())
+    if lib().tmpc_mc_set_fused(h.ptr, MC_FUSED[fused]) != 0:
         raise RuntimeError(h.error())
     if lib().tmpc_mc_set_warm_start(h.ptr, int(bool(warm_start))) != 0:
         raise RuntimeError(h.error())
@@ -387,6 +398,7 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
         if lib().tmpc_mc_get_physics_error(h.ptr, B, ptr(out["err2_physics"])) != 0:
             raise RuntimeError(h.error())
         out["tracking_error_physics"] = np.sqrt(out["err2_physics"]) / (T * physics_substeps)
+    out["fused"] = bool(lib().tmpc_mc_last_fused(h.ptr))
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
     out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve

@@ -58,6 +58,8 @@ struct tmpc_handle {
     double *mc_cap_dev = nullptr; // its record in the arena: [mc_cap_T][2 nx + nu]
     int mc_cap_T = 0;
     int mc_warm = 0;             // closed loop: hand every solve the working set of the trajectory's previous solve of the same variant
+    int mc_fused = TMPC_MC_FUSED_AUTO;   // closed loop: one fused launch for all T steps (tmpc_mc_set_fused)
+    int mc_last_fused = 0;       // what the last tmpc_mc_run did
     double plant_par[7] = {0, 0, 0, 0, 0, 0, 0};
     int kernel_path = TMPC_PATH_AUTO;
     int blk_blocks = 0;          // workgroups the block-kernel workspace is sized for
@@ -935,6 +937,15 @@ int tmpc_mc_set_warm_start(tmpc_handle *h, int on) {
     return TMPC_OK;
 }
 
+int tmpc_mc_set_fused(tmpc_handle *h, int mode) {
+    if (!h) return TMPC_E_INVALID;
+    if (mode != TMPC_MC_FUSED_OFF && mode != TMPC_MC_FUSED_ON && mode != TMPC_MC_FUSED_AUTO) { h->err = "tmpc_mc_set_fused: mode is TMPC_MC_FUSED_OFF / _ON / _AUTO"; return TMPC_E_INVALID; }
+    h->mc_fused = mode;
+    return TMPC_OK;
+}
+
+int tmpc_mc_last_fused(const tmpc_handle *h) { return h ? h->mc_last_fused : 0; }
+
 }  // extern "C"
 
 namespace {
@@ -962,7 +973,7 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     if (rc) return rc;
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
-    const size_t need = 256 * 48 + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
+    const size_t need = 256 * 52 + sizeof(tmpc::McFused) + 8 * t_ + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
                         8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu) +
                         (rp ? b * t_ * (8 * ((N + 1) * nu + nx) + 8 * (3 * nx + nu) + 4 * 3) : 0);
     // what the previous run left in the arena is gone from here on, whether this run gets as far as replacing it or not
@@ -1089,10 +1100,66 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             HIP_TRY(h, hipMemsetAsync(st.trace_f, 0, b * t_ * (3 * nx + nu) * 8, h->stream));
             HIP_TRY(h, hipMemsetAsync(st.trace_i, 0, b * t_ * 3 * 4, h->stream));
         }
-        // Per time step: the solve launch(es) -- one per problem variant in use -- and ONE launch of the state machines
-        // (round 3: mc_pre, the variant check, the solve, mc_post, mc_tube).  With injected packets nothing is solved.
         HIP_TRY(h, tmpc::launch_mc_pre(m, st, B, ref[0], h->stream));
-        for (int t = 0; t < T; ++t) {
+        // ONE launch for the whole sweep where the controller has one problem and it runs on the wave kernel: a wave keeps its
+        // trajectory for all T steps, solve and state machines alternating inside the kernel (tmpc_fused.hip).  The work item of
+        // that launch is a trajectory, T solves long: with B a little above a multiple of the resident waves the last round
+        // of trajectories would run on a nearly empty card, so TMPC_MC_FUSED_AUTO fuses when the rounds are at least 85 % full
+        // (or there is a single round) and otherwise keeps the launch per time step, whose work item is one solve.
+        h->mc_last_fused = 0;
+        bool fuse = !rp && !extended && h->mc_fused != TMPC_MC_FUSED_OFF && !use_block(h, h->v[0]);
+        if (fuse && h->mc_fused == TMPC_MC_FUSED_AUTO) {
+            const int64_t slots = tmpc::resident_waves(h->v[0].shape, h->n_cu);
+            const int64_t rounds = slots > 0 ? (B + slots - 1) / slots : 0;
+            fuse = rounds == 1 || (rounds > 0 && static_cast<double>(B) >= 0.85 * static_cast<double>(rounds * slots));
+        }
+        if (fuse) {
+            tmpc::McFused mf{};
+            if ((r2 = up(ref, t_ * 8, reinterpret_cast<const void **>(&mf.ref_seq)))) return r2;
+            Variant &v = h->v[0];
+            long long *ticks = nullptr;
+            if (h->want_ticks) {
+                if (B > h->ticks_cap) {
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    if (h->d_ticks) (void)hipFree(h->d_ticks);
+                    h->d_ticks = nullptr; h->ticks_cap = 0;
+                    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->d_ticks), static_cast<size_t>(B) * sizeof(long long)));
+                    h->ticks_cap = B;
+                }
+                ticks = h->d_ticks;
+                h->ticks_n = B;
+                HIP_TRY(h, hipMemsetAsync(ticks, 0, static_cast<size_t>(B) * sizeof(long long), h->stream));
+            }
+            v.d.ticks = ticks;
+            st.ticks = ticks;
+            if (tmpc::parks_in_lds(v.shape)) {
+                v.d.save = nullptr;
+            } else {
+                const size_t rs = static_cast<size_t>(2 * v.shape.dp + v.shape.ds + 2 * v.shape.cp + v.shape.cs);
+                const size_t need_save = static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(float);
+                if (need_save > h->save_bytes) {
+                    HIP_TRY(h, hipStreamSynchronize(h->stream));
+                    if (h->save_buf) (void)hipFree(h->save_buf);
+                    h->save_buf = nullptr; h->save_bytes = 0;
+                    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->save_buf), need_save));
+                    h->save_bytes = need_save;
+                }
+                v.d.save = h->save_buf;
+            }
+            mf.m = m; mf.st = st; mf.T = T;
+            const tmpc::McFused *d_mf = nullptr;            // the record itself lives in the arena: the kernel reads it field by field
+            if ((r2 = up(&mf, sizeof(mf), reinterpret_cast<const void **>(&d_mf)))) return r2;
+            hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
+            h->ev0 = e0; h->ev1 = e1;
+            HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+            HIP_TRY(h, tmpc::launch_solve_mc(v.d, v.shape, B, h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, ws[0], d_mf, &h->wc, h->n_cu, h->stream));
+            HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+            h->timed = true;
+            h->mc_last_fused = 1;
+        }
+        // Otherwise, per time step: the solve launch(es) -- one per problem variant in use -- and ONE launch of the state machines
+        // (round 3: mc_pre, the variant check, the solve, mc_post, mc_tube).  With injected packets nothing is solved.
+        for (int t = 0; t < T && !fuse; ++t) {
             if (!rp) {
                 int r3 = enqueue(h, B, st.x_hat, st.ref_k, extended ? st.gamma : nullptr, h->d_u, h->d_x0, h->d_ss, nullptr, h->d_st, h->d_it, ws, true);
                 if (r3) return r3;

@@ -177,6 +177,19 @@ hipError_t launch_mc_pre(const McModel &m, const McState &st, int64_t B, double 
 hipError_t launch_mc_step(const McModel &m, const McState &st, int t, int T, int64_t B, double ref_t, double ref_next, const double *u_nom,
                           const double *x_nom0, const double *xu_ss, const int32_t *status, const int32_t *iters, hipStream_t stream);
 
+// Fused closed loop (tmpc_fused.hip: the wave kernel with the state machines inside, a trajectory per work item): available for
+// every wave shape; one problem variant (the plain controllers: the extended one changes its problem from step to step)
+struct McFused {
+    McModel m;
+    McState st;
+    int T;
+    const double *ref_seq;               // [T] reference of every time step (device)
+};
+hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &shape, int64_t B, double *u_nom, double *x_nom0, double *xu_ss,
+                           int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc /* device */, WorkCounter *wc, int n_cu, hipStream_t stream);
+// resident waves of the persistent grid of a shape (work items in flight): the host's choice between one fused launch and T launches
+int resident_waves(const KernelShape &shape, int n_cu);
+
 // LP kernel (tmpc_lp.hip): rows scaled to unit norm, h scaled by hm so that max |h| = 1
 struct LpDevice {
     int d, nr, nrp;       // dimension, rows, row stride (multiple of 64)

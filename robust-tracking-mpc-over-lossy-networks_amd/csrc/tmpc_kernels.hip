@@ -46,6 +46,9 @@
 
 #include "tmpc_device.hpp"
 #include "tmpc_wave.hpp"
+#if !defined(TMPC_HOST_SIM)
+#include "tmpc_mc_step.hpp"
+#endif
 
 namespace tmpc {
 
@@ -407,13 +410,37 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
     wave_reduce_to_lds<KT + KC + 1, SH::RR>(acc, red, csums, lane);
 }
 
-template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
-__global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
-    const DeviceQP qp, const int variant_id, const int64_t B,
+// FUSED = true: the FUSED closed loop (tmpc_fused.hip).  An item of the work counter is then a TRAJECTORY: the wave that draws it
+// solves its QP at t = 0 .. T-1 and runs the trajectory's state machines (mcstep::mc_step_wave, tmpc_mc_step.hpp) between two
+// solves -- no launch, no host and no other wave between the steps of a trajectory, and the launch's tail (the waves that got
+// the slowest instances last) is paid once per sweep instead of once per time step.  The solve reads the estimate and the
+// reference the state machines wrote (mc.st.x_hat, mc.st.ref_k: plain pointers, x_k / ref are not used) and the state machines
+// read the solve's outputs through the kernel's own pointers; a device-scope fence stands on either side.
+// The closed loop's record (model, state arrays, T, the reference sequence) lies in device memory and is read through the constant
+// address space from an opaque copy of its address: a scalar load per field where it is used.  As a by-value kernel argument its
+// hundred-odd scalar registers stayed live through the whole solve (81 ... 113 spilled vector registers in the two-waves-per-SIMD shapes).
+struct McNone {};
+template <bool FUSED> using McArg = std::conditional_t<FUSED, const McFused *, McNone>;
+#if !defined(TMPC_HOST_SIM)
+typedef const __attribute__((address_space(4))) McFused *McRecord;
+__device__ __forceinline__ McRecord mc_record(const McFused *p) {
+    unsigned lo = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)), hi = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return (McRecord)((static_cast<uintptr_t>(hi) << 32) | lo);
+}
+#endif
+
+// The body of both kernels below (inlined into each: one persistent workgroup per CU, a wave per work item)
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, bool FUSED>
+__device__ __forceinline__ void solve_body(
+    const DeviceQP &qp, const int variant_id, const int64_t B,
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters,
-    const int32_t *ws_in, int32_t *ws_out, unsigned long long *__restrict__ next_item) {      // (ws_in may alias ws_out: the closed loop updates the records in place)
+    const int32_t *ws_in, int32_t *ws_out, unsigned long long *__restrict__ next_item,      // (ws_in may alias ws_out: the closed loop updates the records in place)
+    const McArg<FUSED> mc) {
     using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
     using WL = WaveLds<SH>;
     constexpr int RS = SH::RS, FD = SH::FD, FC = SH::FC, NDP = SH::NDP, NCCP = SH::NCCP, KT = SH::KT, WCAP = SH::WCAP, LDG = SH::LDG;
@@ -498,9 +525,23 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         if (variant != nullptr && variant[b] != variant_id) continue;
         if (variant == nullptr && variant_id != 0) continue;
 
+        int n_steps = 1;
+#if !defined(TMPC_HOST_SIM)
+        if constexpr (FUSED) n_steps = mc_record(mc)->T;
+#endif
+        for (int t_mc = 0; t_mc < n_steps; ++t_mc) {        // (FUSED: the time steps of trajectory b; otherwise the one solve of instance b)
         // ------------------------------------------------------------ per-instance data
         TMPC_REFRESH();
-        if (lane < nx) { xin[lane] = x_k[b * nx + lane]; xin[nx + lane] = ref[b * nx + lane]; }
+#if !defined(TMPC_HOST_SIM)
+        if constexpr (FUSED) {
+            const McRecord mr = mc_record(mc);
+            const double *xh = mr->st.x_hat, *rk = mr->st.ref_k;
+            if (lane < nx) { xin[lane] = xh[b * nx + lane]; xin[nx + lane] = rk[b * nx + lane]; }
+        } else
+#endif
+        {
+            if (lane < nx) { xin[lane] = x_k[b * nx + lane]; xin[nx + lane] = ref[b * nx + lane]; }
+        }
         wave_lds_fence();
         int st = TMPC_STATUS_MAX_ITER;
         int it_done = 0;
@@ -1490,8 +1531,48 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
         if (b == 0 && lane == 0 && qp.dbg) { for (int p_ = 0; p_ < 16; ++p_) qp.dbg[p_] = tph[p_]; }
 #endif
         wave_lds_fence();
+#if !defined(TMPC_HOST_SIM)
+        if constexpr (FUSED) {
+            // the trajectory's state machines for step t_mc: packet, losses, actuator, statistics, plant, estimator, next reference.
+            // Their 128 doubles of hand-round space are the head of the (idle) transposition tile.
+            TMPC_REFRESH();
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");         // the solve's outputs, written lane by lane, are read across lanes
+            const McRecord mr = mc_record(mc);
+            const int t_next = t_mc + 1 < n_steps ? t_mc + 1 : t_mc;
+            const double *rseq = mr->ref_seq;
+            const bool alive = mcstep::mc_step_wave(mr->m, mr->st, t_mc, n_steps, b, rseq[t_mc], rseq[t_next], u_nom, x_nom0, xu_ss, status,
+                                                    iters, *reinterpret_cast<double (*)[mcstep::V_COUNT][mcstep::MAXN]>(red), lane);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");         // x_hat, ref_k of the next solve
+            wave_lds_fence();
+            if (!alive) break;                                          // (R-MPC: the trajectory ended on an infeasible solve)
+        }
+#endif
+        }
     }
 }
+
+// tmpc_solve_batch and the per-step closed loop: a work item is one QP
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
+__global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
+    const DeviceQP qp, const int variant_id, const int64_t B,
+    const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
+    double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
+    double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters,
+    const int32_t *ws_in, int32_t *ws_out, unsigned long long *__restrict__ next_item) {
+    solve_body<NV, DP, DS, KC, CP, CS, WPB, false>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
+                                                   next_item, McNone{});
+}
+#if !defined(TMPC_HOST_SIM)
+// the fused closed loop (tmpc_mc_run with one problem): a work item is one TRAJECTORY, all of its T steps
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
+__global__ __launch_bounds__(WAVE *WPB, 1) void closed_loop_kernel(
+    const DeviceQP qp, const int64_t B, double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
+    int32_t *__restrict__ status, int32_t *__restrict__ iters, int32_t *ws, unsigned long long *__restrict__ next_item,
+    const McFused *mc) {
+    solve_body<NV, DP, DS, KC, CP, CS, WPB, true>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, xu_ss, nullptr, status, iters, ws, ws,
+                                                  next_item, mc);
+}
+#endif
 
 // LDS of a workgroup: per-wave workspaces, the shared model, and `grows` (+ 1 zero) rows of the dense functionals
 template <class SH>
@@ -1534,11 +1615,11 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     return hipSuccess;
 }
 #else
-template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, bool FUSED = false>
 hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, WorkCounter *wc, int n_cu,
-                      hipStream_t stream) {
+                      hipStream_t stream, McArg<FUSED> mc = McArg<FUSED>{}) {
     using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
     const size_t lds = kernel_lds_bytes<SH>(WPB, 4 * qp.nks);
     if (lds > 160 * 1024) return hipErrorInvalidValue;       // (tmpc_api.cpp checks lds_bytes() before it accepts the wave path)
@@ -1553,8 +1634,10 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
         (void)hipGetDevice(&dev_id);
         std::lock_guard<std::mutex> guard(attr_mutex);
         if (dev_id < 0 || dev_id >= 64 || attr_lds[dev_id] < lds) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&solve_kernel<NV, DP, DS, KC, CP, CS, WPB>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            const void *fn = nullptr;
+            if constexpr (FUSED) fn = reinterpret_cast<const void *>(&closed_loop_kernel<NV, DP, DS, KC, CP, CS, WPB>);
+            else fn = reinterpret_cast<const void *>(&solve_kernel<NV, DP, DS, KC, CP, CS, WPB>);
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
             if (e != hipSuccess) return e;
             if (dev_id >= 0 && dev_id < 64) attr_lds[dev_id] = lds;
         }
@@ -1571,9 +1654,13 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
         if (e0 != hipSuccess) return e0;
         wc->pos = 0;
     }
-    hipLaunchKernelGGL((solve_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
-                       qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
-                       wc->ring + wc->pos);
+    if constexpr (FUSED)
+        hipLaunchKernelGGL((closed_loop_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
+                           qp, B, u_nom, x_nom0, xu_ss, status, iters, ws_out, wc->ring + wc->pos, mc);
+    else
+        hipLaunchKernelGGL((solve_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
+                           qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
+                           wc->ring + wc->pos);
     ++wc->pos;
     return hipGetLastError();
 }
@@ -1604,6 +1691,27 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
     X(8, 0, 2, 0, 0, 0) X(8, 0, 4, 0, 0, 0) X(12, 0, 2, 0, 0, 0) X(12, 0, 4, 0, 0, 0) X(16, 0, 2, 0, 0, 0) X(16, 0, 4, 0, 0, 0) \
     X(11, 1, 0, 5, 4, 0) X(12, 1, 0, 5, 4, 0) X(22, 2, 0, 5, 4, 0) X(24, 2, 0, 5, 4, 0) X(15, 1, 0, 4, 7, 0) X(16, 1, 0, 4, 7, 0) X(26, 2, 0, 4, 7, 0)
 #endif
+
+#ifdef TMPC_FUSED_TU
+// tmpc_fused.hip: this translation unit holds the FUSED = true instantiations and nothing else (compiled next to the main one)
+hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, double *u_nom, double *x_nom0, double *xu_ss,
+                           int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, WorkCounter *wc, int n_cu, hipStream_t stream) {
+#define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
+    if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
+        return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>(), true>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, \
+                                                                                         xu_ss, nullptr, status, iters, ws, ws, wc, n_cu, stream, mc);
+    TMPC_SHAPES(TMPC_CASE)
+#undef TMPC_CASE
+    return hipErrorInvalidValue;
+}
+#else
+int resident_waves(const KernelShape &s, int n_cu) {
+#define TMPC_RW(A, B_, C, D, E, F) \
+    if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F) return n_cu * waves_per_block<A, B_, C, D, E, F>();
+    TMPC_SHAPES(TMPC_RW)
+#undef TMPC_RW
+    return 0;
+}
 
 size_t lds_bytes(const KernelShape &s, int grows) {
 #define TMPC_LDS(A, B_, C, D, E, F) \
@@ -1667,5 +1775,7 @@ hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id
 #undef TMPC_CASE
     return hipErrorInvalidValue;
 }
+
+#endif      // TMPC_FUSED_TU
 
 }  // namespace tmpc
