@@ -415,7 +415,7 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
 // solves -- no launch, no host and no other wave between the steps of a trajectory, and the launch's tail (the waves that got
 // the slowest instances last) is paid once per sweep instead of once per time step.  The solve reads the estimate and the
 // reference the state machines wrote (mc.st.x_hat, mc.st.ref_k: plain pointers, x_k / ref are not used) and the state machines
-// read the solve's outputs through the kernel's own pointers; a device-scope fence stands on either side.
+// read the solve's outputs through the kernel's own pointers; a fence stands on either side.
 // The closed loop's record (model, state arrays, T, the reference sequence) lies in device memory and is read through the constant
 // address space from an opaque copy of its address: a scalar load per field where it is used.  As a by-value kernel argument its
 // hundred-odd scalar registers stayed live through the whole solve (81 ... 113 spilled vector registers in the two-waves-per-SIMD shapes).
@@ -1536,13 +1536,15 @@ __device__ __forceinline__ void solve_body(
             // the trajectory's state machines for step t_mc: packet, losses, actuator, statistics, plant, estimator, next reference.
             // Their 128 doubles of hand-round space are the head of the (idle) transposition tile.
             TMPC_REFRESH();
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");         // the solve's outputs, written lane by lane, are read across lanes
+            // (workgroup scope: writer and reader are lanes of the SAME wave, the CU's own L1 serves both -- the wait for the stores, no L2
+            // write-back and no invalidate as at device scope)
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the solve's outputs, written lane by lane, are read across lanes
             const McRecord mr = mc_record(mc);
             const int t_next = t_mc + 1 < n_steps ? t_mc + 1 : t_mc;
             const double *rseq = mr->ref_seq;
             const bool alive = mcstep::mc_step_wave(mr->m, mr->st, t_mc, n_steps, b, rseq[t_mc], rseq[t_next], u_nom, x_nom0, xu_ss, status,
                                                     iters, *reinterpret_cast<double (*)[mcstep::V_COUNT][mcstep::MAXN]>(red), lane);
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");         // x_hat, ref_k of the next solve
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // x_hat, ref_k of the next solve
             wave_lds_fence();
             if (!alive) break;                                          // (R-MPC: the trajectory ended on an infeasible solve)
         }
