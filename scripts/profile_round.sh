@@ -28,6 +28,9 @@ for cfg in config3 config5; do
   python3 scripts/pmc_summary.py solve_ gpurun_out/pmc_${tag}_${cfg}_a gpurun_out/pmc_${tag}_${cfg}_b > gpurun_out/pmc_${tag}_${cfg}_summary.txt
   cat gpurun_out/pmc_${tag}_${cfg}_summary.txt
 done
+# ---- the closed loop (tmpc_mc_run): the fused launch (closed_loop_kernel: all T steps of 4096 trajectories) and the launch pair per step, as bench.py times them
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_closed_loop -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/prof_${tag}_closed_loop.json 2> gpurun_out/prof_${tag}_closed_loop.err
+python3 scripts/trace_summary.py gpurun_out/prof_${tag}_closed_loop > gpurun_out/summ_${tag}_closed_loop_kernel_trace_summary.txt
 # summaries written here, on the box, from this run's files only (what gets copied into profiles/)
 python3 scripts/trace_summary.py gpurun_out/prof_$tag > gpurun_out/summ_${tag}_bench_kernel_trace_summary.txt
 for cfg in config3 config5; do python3 scripts/trace_summary.py gpurun_out/prof_${tag}_$cfg > gpurun_out/summ_${tag}_${cfg}_kernel_trace_summary.txt; done
