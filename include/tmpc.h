@@ -214,9 +214,10 @@ int tmpc_debug_dump_lp_layout(int32_t d, int32_t nr, const double *H, const doub
  * of the reference's Monte-Carlo loop (Results/results_linear_system.py:209-259,291; with extended != 0
  * results_linear_system_with_extendedMPC.py:247-378) -- controller packet, packet losses in both directions,
  * consistent actuator with nominal model and ancillary feedback (SmartActuator.py:125-231), plant update,
- * estimator / robust estimator (Estimator.py:9-161) -- run as per-trajectory state machines between the solve
- * launches (one wavefront per trajectory, ONE launch per time step next to the solve's), on the handle's stream; only the
- * statistics return to the host.
+ * estimator / robust estimator (Estimator.py:9-161) -- run as per-trajectory state machines, one wavefront per trajectory,
+ * on the handle's stream: INSIDE the solve kernel, between two solves of the trajectory, where the controller has one
+ * QP (one launch for the whole sweep; tmpc_mc_set_fused below), else in ONE launch per time step next to the solve's.
+ * Only the statistics return to the host.
  *
  *   in   p_loss B        loss probability of the trajectory (both directions)
  *        ref    T        position reference; the solve gets ref_t = [ref[t], 0, ...]   (:240)

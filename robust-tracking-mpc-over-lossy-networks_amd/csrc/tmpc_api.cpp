@@ -1150,6 +1150,17 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             const tmpc::McFused *d_mf = nullptr;            // the record itself lives in the arena: the kernel reads it field by field
             if ((r2 = up(&mf, sizeof(mf), reinterpret_cast<const void **>(&d_mf)))) return r2;
             hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
+            if (h->pool_used < 4096) {                      // (the launch counts in tmpc_kernel_ms_total like any solve launch)
+                if (h->pool_used == h->pool.size()) {
+                    hipEvent_t a = nullptr, b2 = nullptr;
+                    HIP_TRY(h, hipEventCreate(&a));
+                    HIP_TRY(h, hipEventCreate(&b2));
+                    h->pool.emplace_back(a, b2);
+                }
+                e0 = h->pool[h->pool_used].first;
+                e1 = h->pool[h->pool_used].second;
+                ++h->pool_used;
+            }
             h->ev0 = e0; h->ev1 = e1;
             HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
             HIP_TRY(h, tmpc::launch_solve_mc(v.d, v.shape, B, h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, ws[0], d_mf, &h->wc, h->n_cu, h->stream));
