@@ -398,7 +398,8 @@ def mc_run(h: Handle, p_loss, ref, th_u, ga_u, w, x0=None, Z=None, extended: boo
         if lib().tmpc_mc_get_physics_error(h.ptr, B, ptr(out["err2_physics"])) != 0:
             raise RuntimeError(h.error())
         out["tracking_error_physics"] = np.sqrt(out["err2_physics"]) / (T * physics_substeps)
-    out["fused"] = bool(lib().tmpc_mc_last_fused(h.ptr))
+    out["loop_mode"] = int(lib().tmpc_mc_last_fused(h.ptr))       # 1: one launch per sweep; 2: one launch per problem and step; 0: + a state-machine launch
+    out["fused"] = out["loop_mode"] == 1
     out["tracking_error"] = np.sqrt(out["err2"]) / T
     out["consistent_estimate_error"] = float(out["consistent"].max()) if B else 0.0
     out["iters_mean"] = float(out["iters_sum"].sum()) / max(B * T, 1)            # interior-point iterations per solve

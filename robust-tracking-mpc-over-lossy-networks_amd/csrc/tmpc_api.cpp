@@ -973,7 +973,7 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
     if (rc) return rc;
     const size_t nx = h->nx, nu = h->nu, N = h->N, b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
     // upper bound of what the carve-outs below need (each rounded up to 256 B)
-    const size_t need = 256 * 52 + sizeof(tmpc::McFused) + 8 * t_ + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
+    const size_t need = 256 * 54 + sizeof(tmpc::McFused) + 8 * t_ + b + 8 * (4 * nx * nx + 4 * nu * nx + static_cast<size_t>(rZ) * (nx + 1) + b * (2 + (host_draws ? 2 * t_ + t_ * nx : 0)) + nx) +
                         8 * b * (6 * nx + (N + 1) * nu + nu + 5) + 4 * b * 8 + 2 * b + 2 * 4 * b * tmpc::WS_STRIDE + 8 * t_ * (2 * nx + nu) +
                         (rp ? b * t_ * (8 * ((N + 1) * nu + nx) + 8 * (3 * nx + nu) + 4 * 3) : 0);
     // what the previous run left in the arena is gone from here on, whether this run gets as far as replacing it or not
@@ -1113,10 +1113,11 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             const int64_t rounds = slots > 0 ? (B + slots - 1) / slots : 0;
             fuse = rounds == 1 || (rounds > 0 && static_cast<double>(B) >= 0.85 * static_cast<double>(rounds * slots));
         }
-        if (fuse) {
-            tmpc::McFused mf{};
-            if ((r2 = up(ref, t_ * 8, reinterpret_cast<const void **>(&mf.ref_seq)))) return r2;
-            Variant &v = h->v[0];
+        // the extended controller (two problems, two kernel shapes): per time step ONE launch per problem with the state machines of
+        // its trajectories inside (closed_loop_step_kernel) -- two launches per step where the plain per-step loop has three
+        const bool step_fuse = !rp && extended && h->mc_fused != TMPC_MC_FUSED_OFF && !use_block(h, h->v[0]) && !use_block(h, h->v[1]);
+        // per-solve tick buffer and the hand-over save slots of the wave kernel, as enqueue() provides them per call
+        auto prepare_wave = [&](int nvar) -> int {
             long long *ticks = nullptr;
             if (h->want_ticks) {
                 if (B > h->ticks_cap) {
@@ -1130,22 +1131,69 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
                 h->ticks_n = B;
                 HIP_TRY(h, hipMemsetAsync(ticks, 0, static_cast<size_t>(B) * sizeof(long long), h->stream));
             }
-            v.d.ticks = ticks;
             st.ticks = ticks;
-            if (tmpc::parks_in_lds(v.shape)) {
-                v.d.save = nullptr;
-            } else {
-                const size_t rs = static_cast<size_t>(2 * v.shape.dp + v.shape.ds + 2 * v.shape.cp + v.shape.cs);
-                const size_t need_save = static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(float);
-                if (need_save > h->save_bytes) {
-                    HIP_TRY(h, hipStreamSynchronize(h->stream));
-                    if (h->save_buf) (void)hipFree(h->save_buf);
-                    h->save_buf = nullptr; h->save_bytes = 0;
-                    HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->save_buf), need_save));
-                    h->save_bytes = need_save;
+            // (a slice of the save buffer per problem)
+            size_t need_save = 0, off_save[2] = {0, 0};
+            for (int k = 0; k < nvar; ++k) {
+                Variant &v = h->v[k];
+                v.d.ticks = ticks;
+                off_save[k] = need_save;
+                if (!tmpc::parks_in_lds(v.shape)) {
+                    const size_t rs = static_cast<size_t>(2 * v.shape.dp + v.shape.ds + 2 * v.shape.cp + v.shape.cs);
+                    need_save += static_cast<size_t>(h->n_cu) * 8 * 2 * rs * 64 * sizeof(float);
                 }
-                v.d.save = h->save_buf;
             }
+            if (need_save > h->save_bytes) {
+                HIP_TRY(h, hipStreamSynchronize(h->stream));
+                if (h->save_buf) (void)hipFree(h->save_buf);
+                h->save_buf = nullptr; h->save_bytes = 0;
+                HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(&h->save_buf), need_save));
+                h->save_bytes = need_save;
+            }
+            for (int k = 0; k < nvar; ++k)
+                h->v[k].d.save = tmpc::parks_in_lds(h->v[k].shape) ? nullptr : h->save_buf + off_save[k] / sizeof(float);
+            return TMPC_OK;
+        };
+        if (step_fuse) {
+            tmpc::McFused mf{};
+            if ((r2 = up(ref, t_ * 8, reinterpret_cast<const void **>(&mf.ref_seq)))) return r2;
+            if ((r2 = prepare_wave(2))) return r2;
+            uint8_t *gam[2] = {st.gamma, nullptr};          // selector read in a step / arrival flags written in it: swapped every step
+            if ((r2 = dalloc(b, reinterpret_cast<void **>(&gam[1])))) return r2;
+            HIP_TRY(h, hipMemsetAsync(gam[1], 1, b, h->stream));
+            mf.m = m; mf.st = st; mf.T = T;
+            const tmpc::McFused *d_mf = nullptr;
+            if ((r2 = up(&mf, sizeof(mf), reinterpret_cast<const void **>(&d_mf)))) return r2;
+            // (Measured and dropped: the two launches of a step on two streams, so that the second one's workgroups start on the CUs the
+            // first one's tail leaves idle -- config 4 extended 0.27 -> 0.28 s: the fork / join events of every step cost more.)
+            for (int t = 0; t < T; ++t) {
+                hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
+                if (h->pool_used < 4096) {
+                    if (h->pool_used == h->pool.size()) {
+                        hipEvent_t a = nullptr, b2 = nullptr;
+                        HIP_TRY(h, hipEventCreate(&a));
+                        HIP_TRY(h, hipEventCreate(&b2));
+                        h->pool.emplace_back(a, b2);
+                    }
+                    e0 = h->pool[h->pool_used].first;
+                    e1 = h->pool[h->pool_used].second;
+                    ++h->pool_used;
+                }
+                h->ev0 = e0; h->ev1 = e1;
+                HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+                for (int k = 0; k < 2; ++k)
+                    HIP_TRY(h, tmpc::launch_solve_mc_step(h->v[k].d, h->v[k].shape, k, B, gam[t & 1], h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, ws[k],
+                                                          d_mf, t, gam[(t + 1) & 1], &h->wc, h->n_cu, h->stream));
+                HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+            }
+            h->timed = true;
+            h->mc_last_fused = 2;
+            fuse = true;            // (the per-step loop below is skipped)
+        } else if (fuse) {
+            tmpc::McFused mf{};
+            if ((r2 = up(ref, t_ * 8, reinterpret_cast<const void **>(&mf.ref_seq)))) return r2;
+            Variant &v = h->v[0];
+            if ((r2 = prepare_wave(1))) return r2;
             mf.m = m; mf.st = st; mf.T = T;
             const tmpc::McFused *d_mf = nullptr;            // the record itself lives in the arena: the kernel reads it field by field
             if ((r2 = up(&mf, sizeof(mf), reinterpret_cast<const void **>(&d_mf)))) return r2;

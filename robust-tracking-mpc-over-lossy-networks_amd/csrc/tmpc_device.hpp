@@ -187,6 +187,11 @@ struct McFused {
 };
 hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &shape, int64_t B, double *u_nom, double *x_nom0, double *xu_ss,
                            int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc /* device */, WorkCounter *wc, int n_cu, hipStream_t stream);
+// one time step of one problem of the extended controller, the state machines of its trajectories inside (tmpc_fused_step.hip):
+// `variant` is the selector this step reads, `gamma_out` the one it writes for the next step (two buffers, swapped by the caller)
+hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &shape, int variant_id, int64_t B, const uint8_t *variant, double *u_nom,
+                                double *x_nom0, double *xu_ss, int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc /* device */, int t,
+                                uint8_t *gamma_out, WorkCounter *wc, int n_cu, hipStream_t stream);
 // resident waves of the persistent grid of a shape (work items in flight): the host's choice between one fused launch and T launches
 int resident_waves(const KernelShape &shape, int n_cu);
 

@@ -420,7 +420,15 @@ __device__ __forceinline__ void sweep_a_factored(const double *Hct, const double
 // address space from an opaque copy of its address: a scalar load per field where it is used.  As a by-value kernel argument its
 // hundred-odd scalar registers stayed live through the whole solve (81 ... 113 spilled vector registers in the two-waves-per-SIMD shapes).
 struct McNone {};
-template <bool FUSED> using McArg = std::conditional_t<FUSED, const McFused *, McNone>;
+// FUSED = 0: no closed loop in the kernel.  1: a work item is a trajectory, all T steps (closed_loop_kernel).  2: a work item is one
+// QP of time step t, followed by the state machines of its trajectory for that step (closed_loop_step_kernel: the extended controller,
+// whose two problems are two kernel shapes -- one launch per problem and step, none for the state machines).
+struct McStepArg {
+    const McFused *rec;
+    int t;
+    uint8_t *gamma_out;          // arrival flags written by this step = problem selector of the NEXT step (the selector read in this
+};                               // step is the other of two buffers: a trajectory must not be taken by both launches of a step)
+template <int FUSED> using McArg = std::conditional_t<FUSED == 1, const McFused *, std::conditional_t<FUSED == 2, McStepArg, McNone>>;
 #if !defined(TMPC_HOST_SIM)
 typedef const __attribute__((address_space(4))) McFused *McRecord;
 __device__ __forceinline__ McRecord mc_record(const McFused *p) {
@@ -433,7 +441,7 @@ __device__ __forceinline__ McRecord mc_record(const McFused *p) {
 #endif
 
 // The body of both kernels below (inlined into each: one persistent workgroup per CU, a wave per work item)
-template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, bool FUSED>
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, int FUSED>
 __device__ __forceinline__ void solve_body(
     const DeviceQP &qp, const int variant_id, const int64_t B,
     const double *__restrict__ x_k, const double *__restrict__ ref, const uint8_t *__restrict__ variant,
@@ -527,14 +535,15 @@ __device__ __forceinline__ void solve_body(
 
         int n_steps = 1;
 #if !defined(TMPC_HOST_SIM)
-        if constexpr (FUSED) n_steps = mc_record(mc)->T;
+        if constexpr (FUSED == 1) n_steps = mc_record(mc)->T;
 #endif
         for (int t_mc = 0; t_mc < n_steps; ++t_mc) {        // (FUSED: the time steps of trajectory b; otherwise the one solve of instance b)
         // ------------------------------------------------------------ per-instance data
         TMPC_REFRESH();
 #if !defined(TMPC_HOST_SIM)
-        if constexpr (FUSED) {
-            const McRecord mr = mc_record(mc);
+        if constexpr (FUSED != 0) {
+            McRecord mr;
+            if constexpr (FUSED == 1) mr = mc_record(mc); else mr = mc_record(mc.rec);
             const double *xh = mr->st.x_hat, *rk = mr->st.ref_k;
             if (lane < nx) { xin[lane] = xh[b * nx + lane]; xin[nx + lane] = rk[b * nx + lane]; }
         } else
@@ -1532,18 +1541,22 @@ __device__ __forceinline__ void solve_body(
 #endif
         wave_lds_fence();
 #if !defined(TMPC_HOST_SIM)
-        if constexpr (FUSED) {
+        if constexpr (FUSED != 0) {
             // the trajectory's state machines for step t_mc: packet, losses, actuator, statistics, plant, estimator, next reference.
             // Their 128 doubles of hand-round space are the head of the (idle) transposition tile.
             TMPC_REFRESH();
             // (workgroup scope: writer and reader are lanes of the SAME wave, the CU's own L1 serves both -- the wait for the stores, no L2
             // write-back and no invalidate as at device scope)
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // the solve's outputs, written lane by lane, are read across lanes
-            const McRecord mr = mc_record(mc);
-            const int t_next = t_mc + 1 < n_steps ? t_mc + 1 : t_mc;
+            McRecord mr;
+            int t_now = t_mc, t_all = n_steps;
+            uint8_t *gamma_out = nullptr;
+            if constexpr (FUSED == 1) mr = mc_record(mc);
+            else { mr = mc_record(mc.rec); t_now = mc.t; t_all = mr->T; gamma_out = mc.gamma_out; }
+            const int t_next = t_now + 1 < t_all ? t_now + 1 : t_now;
             const double *rseq = mr->ref_seq;
-            const bool alive = mcstep::mc_step_wave(mr->m, mr->st, t_mc, n_steps, b, rseq[t_mc], rseq[t_next], u_nom, x_nom0, xu_ss, status,
-                                                    iters, *reinterpret_cast<double (*)[mcstep::V_COUNT][mcstep::MAXN]>(red), lane);
+            const bool alive = mcstep::mc_step_wave(mr->m, mr->st, t_now, t_all, b, rseq[t_now], rseq[t_next], u_nom, x_nom0, xu_ss, status,
+                                                    iters, *reinterpret_cast<double (*)[mcstep::V_COUNT][mcstep::MAXN]>(red), lane, gamma_out);
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");     // x_hat, ref_k of the next solve
             wave_lds_fence();
             if (!alive) break;                                          // (R-MPC: the trajectory ended on an infeasible solve)
@@ -1561,7 +1574,7 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     double *__restrict__ x_nom, int32_t *__restrict__ status, int32_t *__restrict__ iters,
     const int32_t *ws_in, int32_t *ws_out, unsigned long long *__restrict__ next_item) {
-    solve_body<NV, DP, DS, KC, CP, CS, WPB, false>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
+    solve_body<NV, DP, DS, KC, CP, CS, WPB, 0>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
                                                    next_item, McNone{});
 }
 #if !defined(TMPC_HOST_SIM)
@@ -1571,8 +1584,18 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void closed_loop_kernel(
     const DeviceQP qp, const int64_t B, double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
     int32_t *__restrict__ status, int32_t *__restrict__ iters, int32_t *ws, unsigned long long *__restrict__ next_item,
     const McFused *mc) {
-    solve_body<NV, DP, DS, KC, CP, CS, WPB, true>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, xu_ss, nullptr, status, iters, ws, ws,
-                                                  next_item, mc);
+    solve_body<NV, DP, DS, KC, CP, CS, WPB, 1>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, xu_ss, nullptr, status, iters, ws, ws,
+                                               next_item, mc);
+}
+// the extended controller's closed loop: the QPs of problem `variant_id` at time step mc.t, each followed by its trajectory's state machines
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
+__global__ __launch_bounds__(WAVE *WPB, 1) void closed_loop_step_kernel(
+    const DeviceQP qp, const int variant_id, const int64_t B, const uint8_t *__restrict__ variant,
+    double *__restrict__ u_nom, double *__restrict__ x_nom0, double *__restrict__ xu_ss,
+    int32_t *__restrict__ status, int32_t *__restrict__ iters, int32_t *ws, unsigned long long *__restrict__ next_item,
+    const McStepArg mc) {
+    solve_body<NV, DP, DS, KC, CP, CS, WPB, 2>(qp, variant_id, B, nullptr, nullptr, variant, u_nom, x_nom0, xu_ss, nullptr, status, iters, ws, ws,
+                                               next_item, mc);
 }
 #endif
 
@@ -1617,7 +1640,7 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     return hipSuccess;
 }
 #else
-template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, bool FUSED = false>
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, int FUSED = 0>
 hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, WorkCounter *wc, int n_cu,
@@ -1637,7 +1660,8 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
         std::lock_guard<std::mutex> guard(attr_mutex);
         if (dev_id < 0 || dev_id >= 64 || attr_lds[dev_id] < lds) {
             const void *fn = nullptr;
-            if constexpr (FUSED) fn = reinterpret_cast<const void *>(&closed_loop_kernel<NV, DP, DS, KC, CP, CS, WPB>);
+            if constexpr (FUSED == 1) fn = reinterpret_cast<const void *>(&closed_loop_kernel<NV, DP, DS, KC, CP, CS, WPB>);
+            else if constexpr (FUSED == 2) fn = reinterpret_cast<const void *>(&closed_loop_step_kernel<NV, DP, DS, KC, CP, CS, WPB>);
             else fn = reinterpret_cast<const void *>(&solve_kernel<NV, DP, DS, KC, CP, CS, WPB>);
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
             if (e != hipSuccess) return e;
@@ -1656,9 +1680,12 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
         if (e0 != hipSuccess) return e0;
         wc->pos = 0;
     }
-    if constexpr (FUSED)
+    if constexpr (FUSED == 1)
         hipLaunchKernelGGL((closed_loop_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
                            qp, B, u_nom, x_nom0, xu_ss, status, iters, ws_out, wc->ring + wc->pos, mc);
+    else if constexpr (FUSED == 2)
+        hipLaunchKernelGGL((closed_loop_step_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
+                           qp, variant_id, B, variant, u_nom, x_nom0, xu_ss, status, iters, ws_out, wc->ring + wc->pos, mc);
     else
         hipLaunchKernelGGL((solve_kernel<NV, DP, DS, KC, CP, CS, WPB>), dim3(static_cast<unsigned>(blocks)), dim3(WAVE * WPB), lds, stream,
                            qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
@@ -1694,13 +1721,27 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
     X(11, 1, 0, 5, 4, 0) X(12, 1, 0, 5, 4, 0) X(22, 2, 0, 5, 4, 0) X(24, 2, 0, 5, 4, 0) X(15, 1, 0, 4, 7, 0) X(16, 1, 0, 4, 7, 0) X(26, 2, 0, 4, 7, 0)
 #endif
 
-#ifdef TMPC_FUSED_TU
-// tmpc_fused.hip: this translation unit holds the FUSED = true instantiations and nothing else (compiled next to the main one)
+#if defined(TMPC_FUSED_TU) && TMPC_FUSED_TU == 2
+// tmpc_fused_step.hip: the FUSED = 2 instantiations and nothing else
+hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &s, int variant_id, int64_t B, const uint8_t *variant, double *u_nom,
+                                double *x_nom0, double *xu_ss, int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, int t,
+                                uint8_t *gamma_out, WorkCounter *wc, int n_cu, hipStream_t stream) {
+    const McStepArg arg{mc, t, gamma_out};
+#define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
+    if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
+        return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>(), 2>(qp, variant_id, B, nullptr, nullptr, variant, u_nom, x_nom0, \
+                                                                                      xu_ss, nullptr, status, iters, ws, ws, wc, n_cu, stream, arg);
+    TMPC_SHAPES(TMPC_CASE)
+#undef TMPC_CASE
+    return hipErrorInvalidValue;
+}
+#elif defined(TMPC_FUSED_TU)
+// tmpc_fused.hip: this translation unit holds the FUSED = 1 instantiations and nothing else (compiled next to the main one)
 hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, double *u_nom, double *x_nom0, double *xu_ss,
                            int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, WorkCounter *wc, int n_cu, hipStream_t stream) {
 #define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
-        return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>(), true>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, \
+        return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>(), 1>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, \
                                                                                          xu_ss, nullptr, status, iters, ws, ws, wc, n_cu, stream, mc);
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE

@@ -86,7 +86,8 @@ template <class ModelRec, class StateRec>
 __device__ __forceinline__ bool mc_step_wave(const ModelRec &m, const StateRec &st, const int t, const int T, const int64_t b,
                                              const double ref_t, const double ref_next,
                                              const double *u_nom, const double *x_nom0, const double *xu_ss, const int32_t *status,
-                                             const int32_t *iters, double (&S)[V_COUNT][MAXN], const int lane) {
+                                             const int32_t *iters, double (&S)[V_COUNT][MAXN], const int lane,
+                                             uint8_t *gamma_out = nullptr /* where this step's arrival flag goes instead of st.gamma */) {
     const int nx = m.nx, nu = m.nu, N = m.N;
     if (st.dead[b]) return false;                                                        // results_linear_system.py:262
     const bool replay = st.rp_U != nullptr;      // packets injected by the caller instead of solved (tmpc_mc_replay)
@@ -270,7 +271,7 @@ __device__ __forceinline__ bool mc_step_wave(const ModelRec &m, const StateRec &
             st.consistent[b] = fmax(st.consistent[b], ce);
         }
     }
-    if (lane == 0) st.gamma[b] = static_cast<uint8_t>(gamma);
+    if (lane == 0) (gamma_out ? gamma_out : st.gamma)[b] = static_cast<uint8_t>(gamma);
     if (lx) st.ref_k[b * nx + lane] = (lane == 0) ? ref_next : 0.0;      // ref = [ref_{t+1}, 0, ..] of the next solve (:240)
     if (st.trace_f) {
         // every step of every trajectory (tmpc_mc_replay): x_{t+1}, x_hat_{t+1}, the nominal state of the plant's packet, u_t;

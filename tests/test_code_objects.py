@@ -47,6 +47,13 @@ def test_fused_closed_loop_kernels_match_the_solve_kernels():
         assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"])
     bench = [k for n, k in fused.items() if "closed_loop_kernel<11, 1, 0, 5, 4, 0, 8>" in n]
     assert len(bench) == 1 and bench[0][".vgpr_count"] <= 256 and bench[0][".vgpr_spill_count"] == 0
+    # the extended controller's form: one problem at one time step, the state machines of its trajectories inside
+    step = {n: k for n, k in ks.items() if "::closed_loop_step_kernel<" in n}
+    assert len(step) == 13, sorted(step)
+    for n, k in step.items():
+        shape = n.split("::closed_loop_step_kernel")[1].split("(")[0]
+        limit = 64 if shape.replace(" ", "") == "<12,0,4,0,0,0,8>" else 0
+        assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"])
 
 
 def test_other_kernels_stay_within_their_known_footprint():

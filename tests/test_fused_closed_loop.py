@@ -97,4 +97,25 @@ def test_automatic_choice(hip_lib):
     mpc.set_kernel_path("wave")
     assert run(64)
     ext, _ = common.make_mpc("cartpole", 10, True, extended=True, create=True)
-    assert not ext.run_closed_loop(np.full(64, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True, fused="on")["fused"]
+    e = ext.run_closed_loop(np.full(64, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True, fused="on")
+    assert not e["fused"] and e["loop_mode"] == 2       # two problems: a launch per problem and step, the state machines inside
+    assert ext.run_closed_loop(np.full(64, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True, fused="off")["loop_mode"] == 0
+
+
+@pytest.mark.parametrize("N,warm", [(10, False), (10, True), (20, True)])
+def test_extended_loop_with_the_state_machines_inside_the_solve_launches(hip_lib, N, warm):
+    """The extended controller changes its QP from step to step with the arrival flag (results_linear_system_with_extendedMPC.py:
+    267-279): closed_loop_step_kernel<shape of the problem> solves the trajectories whose flag selects its problem and runs their
+    state machines; the flags a step writes are the selector of the NEXT step (two buffers).  Same numbers as two solve launches
+    + one state-machine launch per step, bit for bit."""
+    nb, T = 200, 60
+    mpc, w = common.make_mpc("cartpole", N, True, extended=True, create=True)
+    p_loss = np.tile(np.arange(10) / 10.0, nb // 10)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=43)
+    ref = np.where(np.arange(T) < T // 2, 0.5, -0.3)
+    off = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=True, warm_start=warm, capture=3, timing=True, fused="off")
+    on = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=True, warm_start=warm, capture=3, timing=True)
+    assert off["loop_mode"] == 0 and on["loop_mode"] == 2
+    _same(on, off, KEYS + ("x_traj", "x_nom_traj", "u_traj"))
+    assert np.all(on["not_optimal"] == 0) and np.all(on["tube_violations"] == 0)
+    assert np.all(on["solve_time_mean"] > 0)
