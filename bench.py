@@ -394,6 +394,27 @@ def main():
                                                "steps: the figure is 250 x the latency of one solve + state machines); per_step_launches: a solve "
                                                "launch + a state-machine launch per step"}
             del mpc20
+            # ... and the reference's second experiment at its own size (results_linear_system_with_extendedMPC.py:133-147: the extended
+            # controller, N = 20, 10 x 20 x 250): two problems, chosen per step by the arrival flag -- one launch per problem and step
+            # with the state machines inside (tmpc_mc_last_fused = 2), against two solve launches + a state-machine launch
+            mpc20x, _ = workloads.make_controller("cartpole", 20, True, extended=True, device=dev_index)
+            mpc20x.run_closed_loop(pl20[:8], ref20[:20], th20[:8, :20], ga20[:8, :20], wd20[:8, :20], extended=True)          # warm-up
+            smallx = {}
+            for warm in (False, True):
+                leg = {}
+                for mode in ("off", None):
+                    ts = time.perf_counter()
+                    cl = mpc20x.run_closed_loop(pl20, ref20, th20, ga20, wd20, extended=True, warm_start=warm, fused=mode)
+                    ts = time.perf_counter() - ts
+                    if mode == "off":
+                        leg["three_launches_per_step"] = {"wall_s": ts, "ms_per_step": ts / 250 * 1e3}
+                        continue
+                    leg.update({"wall_s": ts, "ms_per_step": ts / 250 * 1e3, "MPC_steps_per_s": len(pl20) * 250 / ts, "loop_mode": int(cl["loop_mode"]),
+                                "launches": 500 if cl["loop_mode"] == 2 else 750, "tube_violations": int(cl["tube_violations"].sum()),
+                                "non_optimal_solves": int(cl["not_optimal"].sum())})
+                smallx["warm" if warm else "cold"] = leg
+            ex["closed_loop_small"]["extended"] = {**smallx, "note": "ExtendedTubeTrackingMPC + RobustEstimator + ConsistentActuator, same size"}
+            del mpc20x
             # offline stage extra: support-function LPs over this workload's terminal set in one launch (tmpc_lp_batch)
             Xf = mpc._Xf
             dirs = np.random.default_rng(7).standard_normal((65536, Xf.A.shape[1]))

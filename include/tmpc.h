@@ -276,8 +276,9 @@ int tmpc_mc_set_warm_start(tmpc_handle *h, int on);
  * which wavefront runs it or when.  TMPC_MC_FUSED_AUTO (default): fused when the trajectories fill their rounds on the
  * card's resident wavefronts to at least 85 % (or fit in one round), else per step -- a fused work item is T solves
  * long, a per-step one a single solve.  Fusing needs ONE problem on the one-wave-per-QP kernel: the extended controller
- * (two problems, chosen per step by the arrival flag) takes, unless the mode is TMPC_MC_FUSED_OFF, ONE launch per problem
- * and time step with the state machines of the problem's trajectories inside (two launches per step instead of three);
+ * (two problems, chosen per step by the arrival flag) takes ONE launch per problem and time step with the state machines
+ * of the problem's trajectories inside (two launches per step instead of three: _ON, and _AUTO from one round of resident
+ * wavefronts on -- a smaller batch is bound by the latency of its launches, which the state machines inside lengthen);
  * the workgroup-per-QP kernel and tmpc_mc_replay always take a solve launch per problem and a state-machine launch per
  * step.  tmpc_mc_last_fused: what the last tmpc_mc_run of the handle did -- 1: one launch for the sweep; 2: one launch
  * per problem and step, state machines inside; 0: solve launches + a state-machine launch per step.

@@ -1115,7 +1115,10 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
         }
         // the extended controller (two problems, two kernel shapes): per time step ONE launch per problem with the state machines of
         // its trajectories inside (closed_loop_step_kernel) -- two launches per step where the plain per-step loop has three
-        const bool step_fuse = !rp && extended && h->mc_fused != TMPC_MC_FUSED_OFF && !use_block(h, h->v[0]) && !use_block(h, h->v[1]);
+        // (TMPC_MC_FUSED_AUTO: from one round of resident waves on -- below that a step is the latency of its launches, and the state
+        // machines inside BOTH of them lengthen it: 200 trajectories at N = 20 0.0345 s with three launches per step, 0.0367 s with two)
+        bool step_fuse = !rp && extended && h->mc_fused != TMPC_MC_FUSED_OFF && !use_block(h, h->v[0]) && !use_block(h, h->v[1]);
+        if (step_fuse && h->mc_fused == TMPC_MC_FUSED_AUTO) step_fuse = B >= tmpc::resident_waves(h->v[1].shape, h->n_cu);
         // per-solve tick buffer and the hand-over save slots of the wave kernel, as enqueue() provides them per call
         auto prepare_wave = [&](int nvar) -> int {
             long long *ticks = nullptr;

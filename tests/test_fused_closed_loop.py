@@ -100,6 +100,9 @@ def test_automatic_choice(hip_lib):
     e = ext.run_closed_loop(np.full(64, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True, fused="on")
     assert not e["fused"] and e["loop_mode"] == 2       # two problems: a launch per problem and step, the state machines inside
     assert ext.run_closed_loop(np.full(64, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True, fused="off")["loop_mode"] == 0
+    # automatic: from one round of resident wavefronts on (below that the launches' latency decides, and three short ones win)
+    assert ext.run_closed_loop(np.full(64, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True)["loop_mode"] == 0
+    assert ext.run_closed_loop(np.full(2048, 0.3), ref, device_rng=(1, 0, w["w_bound"]), extended=True)["loop_mode"] == 2
 
 
 @pytest.mark.parametrize("N,warm", [(10, False), (10, True), (20, True)])
@@ -114,7 +117,7 @@ def test_extended_loop_with_the_state_machines_inside_the_solve_launches(hip_lib
     th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=43)
     ref = np.where(np.arange(T) < T // 2, 0.5, -0.3)
     off = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=True, warm_start=warm, capture=3, timing=True, fused="off")
-    on = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=True, warm_start=warm, capture=3, timing=True)
+    on = mpc.run_closed_loop(p_loss, ref, th, ga, dist, extended=True, warm_start=warm, capture=3, timing=True, fused="on")
     assert off["loop_mode"] == 0 and on["loop_mode"] == 2
     _same(on, off, KEYS + ("x_traj", "x_nom_traj", "u_traj"))
     assert np.all(on["not_optimal"] == 0) and np.all(on["tube_violations"] == 0)
