@@ -31,6 +31,12 @@ done
 # ---- the closed loop (tmpc_mc_run): the fused launch (closed_loop_kernel: all T steps of 4096 trajectories) and the launch pair per step, as bench.py times them
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_closed_loop -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > gpurun_out/prof_${tag}_closed_loop.json 2> gpurun_out/prof_${tag}_closed_loop.err
 python3 scripts/trace_summary.py gpurun_out/prof_${tag}_closed_loop > gpurun_out/summ_${tag}_closed_loop_kernel_trace_summary.txt
+CL="python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU --output-format csv -d gpurun_out/pmc_${tag}_cl_a -- $CL > gpurun_out/pmc_${tag}_cl_a.log 2>&1
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc_${tag}_cl_b -- $CL > gpurun_out/pmc_${tag}_cl_b.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_${tag}_cl_f -- $CL > gpurun_out/pmc_${tag}_cl_f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_${tag}_cl_w -- $CL > gpurun_out/pmc_${tag}_cl_w.log 2>&1
+python3 scripts/pmc_summary.py closed_loop_kernel gpurun_out/pmc_${tag}_cl_a gpurun_out/pmc_${tag}_cl_b gpurun_out/pmc_${tag}_cl_f gpurun_out/pmc_${tag}_cl_w > gpurun_out/summ_${tag}_closed_loop_pmc_summary.txt
 # summaries written here, on the box, from this run's files only (what gets copied into profiles/)
 python3 scripts/trace_summary.py gpurun_out/prof_$tag > gpurun_out/summ_${tag}_bench_kernel_trace_summary.txt
 for cfg in config3 config5; do python3 scripts/trace_summary.py gpurun_out/prof_${tag}_$cfg > gpurun_out/summ_${tag}_${cfg}_kernel_trace_summary.txt; done
