@@ -46,9 +46,7 @@
 
 #include "tmpc_device.hpp"
 #include "tmpc_wave.hpp"
-#if !defined(TMPC_HOST_SIM)
 #include "tmpc_mc_step.hpp"
-#endif
 
 namespace tmpc {
 
@@ -429,7 +427,10 @@ struct McStepArg {
     uint8_t *gamma_out;          // arrival flags written by this step = problem selector of the NEXT step (the selector read in this
 };                               // step is the other of two buffers: a trajectory must not be taken by both launches of a step)
 template <int FUSED> using McArg = std::conditional_t<FUSED == 1, const McFused *, std::conditional_t<FUSED == 2, McStepArg, McNone>>;
-#if !defined(TMPC_HOST_SIM)
+#if defined(TMPC_HOST_SIM)
+typedef const McFused *McRecord;
+__device__ __forceinline__ McRecord mc_record(const McFused *p) { return p; }
+#else
 typedef const __attribute__((address_space(4))) McFused *McRecord;
 __device__ __forceinline__ McRecord mc_record(const McFused *p) {
     unsigned lo = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p)), hi = static_cast<unsigned>(reinterpret_cast<uintptr_t>(p) >> 32);
@@ -534,21 +535,16 @@ __device__ __forceinline__ void solve_body(
         if (variant == nullptr && variant_id != 0) continue;
 
         int n_steps = 1;
-#if !defined(TMPC_HOST_SIM)
         if constexpr (FUSED == 1) n_steps = mc_record(mc)->T;
-#endif
         for (int t_mc = 0; t_mc < n_steps; ++t_mc) {        // (FUSED: the time steps of trajectory b; otherwise the one solve of instance b)
         // ------------------------------------------------------------ per-instance data
         TMPC_REFRESH();
-#if !defined(TMPC_HOST_SIM)
         if constexpr (FUSED != 0) {
             McRecord mr;
             if constexpr (FUSED == 1) mr = mc_record(mc); else mr = mc_record(mc.rec);
             const double *xh = mr->st.x_hat, *rk = mr->st.ref_k;
             if (lane < nx) { xin[lane] = xh[b * nx + lane]; xin[nx + lane] = rk[b * nx + lane]; }
-        } else
-#endif
-        {
+        } else {
             if (lane < nx) { xin[lane] = x_k[b * nx + lane]; xin[nx + lane] = ref[b * nx + lane]; }
         }
         wave_lds_fence();
@@ -1540,7 +1536,6 @@ __device__ __forceinline__ void solve_body(
         if (b == 0 && lane == 0 && qp.dbg) { for (int p_ = 0; p_ < 16; ++p_) qp.dbg[p_] = tph[p_]; }
 #endif
         wave_lds_fence();
-#if !defined(TMPC_HOST_SIM)
         if constexpr (FUSED != 0) {
             // the trajectory's state machines for step t_mc: packet, losses, actuator, statistics, plant, estimator, next reference.
             // Their 128 doubles of hand-round space are the head of the (idle) transposition tile.
@@ -1561,7 +1556,6 @@ __device__ __forceinline__ void solve_body(
             wave_lds_fence();
             if (!alive) break;                                          // (R-MPC: the trajectory ended on an infeasible solve)
         }
-#endif
         }
     }
 }
@@ -1577,7 +1571,6 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void solve_kernel(
     solve_body<NV, DP, DS, KC, CP, CS, WPB, 0>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters, ws_in, ws_out,
                                                    next_item, McNone{});
 }
-#if !defined(TMPC_HOST_SIM)
 // the fused closed loop (tmpc_mc_run with one problem): a work item is one TRAJECTORY, all of its T steps
 template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
 __global__ __launch_bounds__(WAVE *WPB, 1) void closed_loop_kernel(
@@ -1597,7 +1590,6 @@ __global__ __launch_bounds__(WAVE *WPB, 1) void closed_loop_step_kernel(
     solve_body<NV, DP, DS, KC, CP, CS, WPB, 2>(qp, variant_id, B, nullptr, nullptr, variant, u_nom, x_nom0, xu_ss, nullptr, status, iters, ws, ws,
                                                next_item, mc);
 }
-#endif
 
 // LDS of a workgroup: per-wave workspaces, the shared model, and `grows` (+ 1 zero) rows of the dense functionals
 template <class SH>
@@ -1621,11 +1613,11 @@ constexpr int waves_per_block() {
 
 #ifdef TMPC_HOST_SIM
 // tests/wavesim: one workgroup of WPB waves on the host execution model; the persistent grid is that one workgroup
-template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB>
+template <int NV, int DP, int DS, int KC, int CP, int CS, int WPB, int FUSED = 0>
 hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const double *x_k, const double *ref,
                       const uint8_t *variant, double *u_nom, double *x_nom0, double *xu_ss, double *x_nom,
                       int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out, WorkCounter *wc, int n_cu,
-                      hipStream_t stream) {
+                      hipStream_t stream, McArg<FUSED> mc = McArg<FUSED>{}) {
     using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, WPB)>;
     const size_t lds = kernel_lds_bytes<SH>(WPB, 4 * qp.nks);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
@@ -1634,8 +1626,13 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
     sim::Dim3 bi, gd;
     bi.x = bi.y = bi.z = 0;                    // workgroup 0 of a grid of one
     sim_rendezvous_total += sim::run_block(WAVE * WPB, lds, bi, gd, [&]() {
-        solve_kernel<NV, DP, DS, KC, CP, CS, WPB>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters,
-                                                  ws_in, ws_out, &next_item);
+        if constexpr (FUSED == 1)
+            closed_loop_kernel<NV, DP, DS, KC, CP, CS, WPB>(qp, B, u_nom, x_nom0, xu_ss, status, iters, ws_out, &next_item, mc);
+        else if constexpr (FUSED == 2)
+            closed_loop_step_kernel<NV, DP, DS, KC, CP, CS, WPB>(qp, variant_id, B, variant, u_nom, x_nom0, xu_ss, status, iters, ws_out, &next_item, mc);
+        else
+            solve_kernel<NV, DP, DS, KC, CP, CS, WPB>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, xu_ss, x_nom, status, iters,
+                                                      ws_in, ws_out, &next_item);
     });
     return hipSuccess;
 }
@@ -1721,7 +1718,7 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
     X(11, 1, 0, 5, 4, 0) X(12, 1, 0, 5, 4, 0) X(22, 2, 0, 5, 4, 0) X(24, 2, 0, 5, 4, 0) X(15, 1, 0, 4, 7, 0) X(16, 1, 0, 4, 7, 0) X(26, 2, 0, 4, 7, 0)
 #endif
 
-#if defined(TMPC_FUSED_TU) && TMPC_FUSED_TU == 2
+#if defined(TMPC_HOST_SIM) || (defined(TMPC_FUSED_TU) && TMPC_FUSED_TU == 2)
 // tmpc_fused_step.hip: the FUSED = 2 instantiations and nothing else
 hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &s, int variant_id, int64_t B, const uint8_t *variant, double *u_nom,
                                 double *x_nom0, double *xu_ss, int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, int t,
@@ -1735,7 +1732,8 @@ hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &s, int va
 #undef TMPC_CASE
     return hipErrorInvalidValue;
 }
-#elif defined(TMPC_FUSED_TU)
+#endif
+#if defined(TMPC_HOST_SIM) || (defined(TMPC_FUSED_TU) && TMPC_FUSED_TU == 1)
 // tmpc_fused.hip: this translation unit holds the FUSED = 1 instantiations and nothing else (compiled next to the main one)
 hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, double *u_nom, double *x_nom0, double *xu_ss,
                            int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, WorkCounter *wc, int n_cu, hipStream_t stream) {
@@ -1747,7 +1745,8 @@ hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, 
 #undef TMPC_CASE
     return hipErrorInvalidValue;
 }
-#else
+#endif
+#if defined(TMPC_HOST_SIM) || !defined(TMPC_FUSED_TU)
 int resident_waves(const KernelShape &s, int n_cu) {
 #define TMPC_RW(A, B_, C, D, E, F) \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F) return n_cu * waves_per_block<A, B_, C, D, E, F>();
@@ -1819,6 +1818,6 @@ hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id
     return hipErrorInvalidValue;
 }
 
-#endif      // TMPC_FUSED_TU
+#endif      // main translation unit
 
 }  // namespace tmpc

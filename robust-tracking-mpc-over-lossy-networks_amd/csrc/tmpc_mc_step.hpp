@@ -2,7 +2,11 @@
 // trajectory (see tmpc_mc.hip for the reference lines).  Called by mc_step_kernel (tmpc_mc.hip: one launch per time step behind the
 // solve launch) and, inlined, by the fused closed-loop kernel (tmpc_fused.hip: a wave keeps its trajectory for all T steps).
 #pragma once
+#ifdef TMPC_HOST_SIM
+#include "hip_sim.hpp"
+#else
 #include <hip/hip_runtime.h>
+#endif
 
 #include <cmath>
 #include <cstdint>
@@ -70,7 +74,11 @@ __device__ __forceinline__ void mc_draws(const StateRec &st, int64_t b, int t, i
 }
 
 // Orders one wave's LDS traffic for the compiler (the hardware runs the DS instructions of a wave in issue order).
+#ifdef TMPC_HOST_SIM
+__device__ __forceinline__ void mc_fence() { sim::wave_fence(); }      // (tests/wavesim: an LDS hand-over between lanes is a rendezvous)
+#else
 __device__ __forceinline__ void mc_fence() { asm volatile("" ::: "memory"); }
+#endif
 
 enum { V_X = 0, V_XN, V_E, V_ET, V_U, V_UN, V_BASE, V_TMP, V_COUNT };
 

@@ -122,6 +122,42 @@ def test_edge_cases_and_the_dense_single_shape_under_sanitizers(binaries, oracle
 
 
 # ---------------------------------------------------------------- the workgroup-per-QP kernel (csrc/tmpc_block.hip)
+def test_fused_closed_loop_source_under_sanitizers(binaries, cartpole, oracle_lib):
+    """closed_loop_kernel (csrc/tmpc_fused.hip: the wave kernel's body with the trajectory's state machines of tmpc_mc_step.hpp between
+    two solves, a wave per trajectory for all T steps) on the host execution model: the loop equals the numpy state machines driven by
+    the ORACLE's solves (the reference's loop body, results_linear_system.py:209-259), and ASan / UBSan / MSan see every access of the
+    state machines -- their LDS hand-overs, the packet buffer, the statistics -- with the per-trajectory arrays as exact-size heap
+    blocks and the solve's outputs poisoned until written."""
+    from LinearMPCOverNetworks import montecarlo
+    from oracle.oracle import Oracle
+    nb, T = 8, 12
+    mpc, w = common.make_mpc("cartpole", 10, True)
+    p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=7)
+    ref = np.where(np.arange(T) < 6, 0.5, -0.3)
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    orc = Oracle(cartpole)
+
+    def packets(x_hat, r, gamma=None):
+        sol = orc.solve(x_hat, r, gamma)
+        u_ss = sol["u_ss"] + sol["x_ss"] @ mpc._K.T
+        return np.ascontiguousarray(np.concatenate([sol["u_nom"], u_ss[:, None, :]], axis=1).transpose(0, 2, 1)), sol["x_nom0"], sol["status"]
+    host = montecarlo.run_remote_tube_mpc(packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist)
+    jobs = [("wavesim", False), ("wavesim_asan", True), ("wavesim_msan", False)]
+    with ThreadPoolExecutor(3) as ex:
+        outs = list(ex.map(lambda j: run_case.run_loop(binaries[j[0]], cartpole, K, Kp, mpc._Z, p_loss, ref, th, ga, dist, warm=j[1], env=SAN_ENV), jobs))
+    for (name, warm), o in zip(jobs, outs):
+        assert_clean(o)
+        np.testing.assert_allclose(o["x_final"], host["x_final"], atol=1e-8, rtol=0, err_msg=name)
+        np.testing.assert_allclose(o["tracking_error"], host["tracking_error"], atol=1e-10, rtol=0, err_msg=name)
+        assert np.array_equal(o["tube_violations"], host["tube_violations"]) and np.all(o["tube_violations"] == 0), name
+        assert np.array_equal(o["not_optimal"], host["not_optimal"]), name
+        assert o["consistent"].max() < 1e-9, name                       # Proposition 1
+    # the warm-started loop does the same steps with fewer interior-point iterations
+    assert outs[1]["iters_sum"].sum() < outs[0]["iters_sum"].sum()
+    assert np.array_equal(outs[0]["iters_sum"], outs[2]["iters_sum"])
+
+
 @pytest.fixture(scope="module")
 def block_binaries():
     return _build_or_skip()

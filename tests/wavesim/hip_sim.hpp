@@ -323,6 +323,7 @@ inline long long sim_clock() { static long long t = 0; return t += 7; }
 #define __builtin_amdgcn_s_memrealtime() sim_clock()
 inline unsigned long long __ballot(bool p) { return sim::ballot(p); }
 inline int __any(bool p) { return sim::ballot(p) != 0ull; }
+inline unsigned long long __umul64hi(unsigned long long a, unsigned long long b) { return static_cast<unsigned long long>((static_cast<unsigned __int128>(a) * b) >> 64); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 #define __builtin_amdgcn_fence(order, scope) sim::wave_fence()

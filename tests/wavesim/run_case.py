@@ -99,3 +99,45 @@ def run_lp(binary, H, h, Cmat, relax=None, relax_by=1.0, env=None, timeout=1800)
     st = np.frombuffer(raw, np.int32, B, 8 * B * (d + 1))
     it = np.frombuffer(raw, np.int32, B, 8 * B * (d + 1) + 4 * B)
     return dict(val=val, x=x, status=st, iters=it, stderr=res.stderr, stdout=res.stdout)
+
+
+def run_loop(binary, d, K, K_anc, Z, p_loss, ref, th_u, ga_u, w, x0=None, smart=False, warm=False, env=None, timeout=3600):
+    """the FUSED closed loop (wavesim --loop: closed_loop_kernel, a wave keeps its trajectory for all T steps) for the plain controller
+    of problem dict `d`; gains K, K_anc (nu, nx), tube cross-section Z (object with .A, .b) or None"""
+    from LinearMPCOverNetworks import _native
+    L = _native.lib()
+    L.tmpc_debug_dump_layout.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
+    h = _native.create(d, -1)
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            lay, loop, out = (os.path.join(tmp, n) for n in ("layout.bin", "loop.bin", "out.bin"))
+            rc = L.tmpc_debug_dump_layout(h.ptr, 0, lay.encode())
+            if rc != 0:
+                raise RuntimeError(f"tmpc_debug_dump_layout failed: {rc}")
+            c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+            th_u, ga_u, w = c(th_u), c(ga_u), c(w)
+            B, T = th_u.shape
+            nx, nu = h.nx, h.nu
+            HZ = np.zeros((0, nx)) if Z is None else c(Z.A)
+            hZ = np.zeros(0) if Z is None else c(Z.b)
+            with open(loop, "wb") as f:
+                np.array([B, T, nx, nu, HZ.shape[0], 0, int(bool(smart)), int(bool(warm))], dtype=np.int64).tofile(f)
+                for a in (np.asarray(d["A"]), np.asarray(d["B"]), K, K_anc, HZ, hZ, p_loss, ref, th_u, ga_u, w,
+                          np.zeros((B, nx)) if x0 is None else x0):
+                    c(a).tofile(f)
+            res = subprocess.run([binary, "--loop", lay, loop, out], capture_output=True, text=True, timeout=timeout,
+                                 env=dict(os.environ, **(env or {})))
+            if res.returncode != 0:
+                raise RuntimeError(f"{os.path.basename(binary)} --loop failed ({res.returncode}):\n{res.stderr[-8000:]}")
+            raw = open(out, "rb").read()
+    finally:
+        _native.destroy(h)
+    o = dict(err2=np.frombuffer(raw, np.float64, B, 0), x_final=np.frombuffer(raw, np.float64, B * nx, 8 * B).reshape(B, nx),
+             consistent=np.frombuffer(raw, np.float64, B, 8 * B * (1 + nx)))
+    off = 8 * B * (2 + nx)
+    for k in ("tube_violations", "not_optimal", "iters_sum"):
+        o[k] = np.frombuffer(raw, np.int32, B, off)
+        off += 4 * B
+    o["tracking_error"] = np.sqrt(o["err2"]) / T
+    o["stderr"], o["stdout"] = res.stderr, res.stdout
+    return o

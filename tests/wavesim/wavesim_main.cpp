@@ -6,6 +6,11 @@
 // product: every byte it reads is either that file or the batch.
 //
 //   wavesim <layout file> [<layout file of variant 1>] <batch file> <output file>
+//   wavesim --loop <layout file> <loop file> <output file>      the FUSED closed loop (closed_loop_kernel: a wave keeps its trajectory
+//                                                               for all T steps, the state machines of tmpc_mc_step.hpp between two solves)
+// loop file  : int64 B, T, nx, nu, rZ, extended(0), smart, warm; doubles A [nx][nx], B [nx][nu], K [nu][nx], K_anc [nu][nx], HZ [rZ][nx], hZ [rZ],
+//              p_loss [B], ref [T], th_u [B][T], ga_u [B][T], w [B][T][nx], x0 [B][nx]
+// its output : err2 [B] doubles, x_final [B][nx], consistent [B]; tube_viol [B], not_optimal [B], iters_sum [B] int32; one uint64 (rendezvous)
 // layout file: include/tmpc.h, tmpc_debug_dump_layout
 // batch file : int64 B, nx; x_k [B][nx], ref [B][nx] doubles; int64 has_variant; variant bytes [B]
 // output file: u_nom [B][N nu], x_nom0 [B][nx], xu_ss [B][nx+nu] doubles, status [B], iters [B] int32, then one uint64:
@@ -14,6 +19,7 @@
 
 #include <cstdio>
 #include <memory>
+#include <string>
 #include <vector>
 
 namespace {
@@ -62,7 +68,63 @@ void read_layout(const char *path, Layout &L) {
 }
 }  // namespace
 
+// The arrays of tmpc::McState as the host side of tmpc_mc_run lays them out (tmpc_api.cpp: mc_run_impl), every one a heap block of its
+// exact size; what the kernel must initialise itself stays poisoned for MemorySanitizer.
+int run_loop(int argc, char **argv) {
+    need(argc == 5, "usage: wavesim --loop <layout> <loop file> <out>");
+    Layout lay;
+    read_layout(argv[2], lay);
+    FILE *f = std::fopen(argv[3], "rb");
+    need(f != nullptr, "cannot open loop file");
+    int64_t hd[8];
+    need(std::fread(hd, 8, 8, f) == 8, "short loop file");
+    const int64_t B = hd[0], T = hd[1], nx = hd[2], nu = hd[3], rZ = hd[4];
+    need(nx == lay.d.nx && nu == lay.d.nu && hd[5] == 0 && B > 0 && T > 0, "loop file does not belong to this layout (plain controller only)");
+    const int N = lay.d.N;
+    auto rd = [&](size_t n) { std::vector<double> v(n); need(n == 0 || std::fread(v.data(), 8, n, f) == n, "short loop file"); return v; };
+    const size_t b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
+    std::vector<double> A = rd(nx * nx), Bm = rd(nx * nu), K = rd(nu * nx), Ka = rd(nu * nx), HZ = rd(rZ * nx), hZ = rd(rZ), pl = rd(b), ref = rd(t_),
+                        th = rd(b * t_), ga = rd(b * t_), w = rd(b * t_ * nx), x0 = rd(b * nx);
+    std::fclose(f);
+    tmpc::McFused mf{};
+    tmpc::McModel &m = mf.m;
+    tmpc::McState &st = mf.st;
+    m.nx = static_cast<int>(nx); m.nu = static_cast<int>(nu); m.N = N; m.extended = 0; m.rZ = static_cast<int>(rZ);
+    m.plant = TMPC_PLANT_LINEAR; m.substeps = 1; m.smart = static_cast<int>(hd[6]);
+    m.A = A.data(); m.B = Bm.data(); m.K = K.data(); m.K_anc = Ka.data(); m.HZ = HZ.data(); m.hZ = hZ.data();
+    std::vector<double> x(x0), xh(x0), xn(x0), Ub(b * (N + 1) * nu, 0.0), ul0(b * nu, 0.0), xn0l(b * nx, 0.0), refk(b * nx, 0.0), err2(b, 0.0), cons(b, 0.0);
+    std::vector<int32_t> q_est(b, 0), q_act(b, 0), s_(b, 0), Th(b, 0), last_lost(b, -1), tube(b, 0), nopt(b, 0), itsum(b, 0);
+    std::vector<uint8_t> gam(b, 1), dead(b, 0);
+    for (size_t i = 0; i < b; ++i) refk[i * nx] = ref[0];                       // mc_pre_kernel: ref = [ref_0, 0, ..] of the first solve
+    st.x = x.data(); st.x_hat = xh.data(); st.x_nom = xn.data(); st.Ubuf = Ub.data(); st.u_latest0 = ul0.data(); st.x_nom0_latest = xn0l.data();
+    st.ref_k = refk.data(); st.err2 = err2.data(); st.consistent = cons.data(); st.err2_phys = nullptr;
+    st.q_est = q_est.data(); st.q_act = q_act.data(); st.s = s_.data(); st.Theta = Th.data(); st.last_lost = last_lost.data();
+    st.tube_viol = tube.data(); st.not_optimal = nopt.data(); st.iters_sum = itsum.data(); st.gamma = gam.data(); st.dead = dead.data();
+    st.p_loss = pl.data(); st.th_u = th.data(); st.ga_u = ga.data(); st.w = w.data();
+    st.rng_on = 0; st.ticks = nullptr; st.tick_sum = st.tick_max = nullptr; st.cap_index = -1; st.cap = nullptr;
+    st.rp_U = st.rp_xn0 = nullptr; st.trace_f = nullptr; st.trace_i = nullptr;
+    mf.T = static_cast<int>(T);
+    mf.ref_seq = ref.data();
+    // outputs of the solve inside the loop: uninitialised on purpose
+    std::unique_ptr<double[]> u(new double[b * N * nu]), xo(new double[b * nx]), ss(new double[b * (nx + nu)]);
+    std::unique_ptr<int32_t[]> sst(new int32_t[b]), it(new int32_t[b]);
+    std::vector<int32_t> ws(hd[7] ? b * tmpc::WS_STRIDE : 0, 0);
+    tmpc::WorkCounter wc;
+    const hipError_t e = tmpc::launch_solve_mc(lay.d, lay.ks, B, u.get(), xo.get(), ss.get(), sst.get(), it.get(), hd[7] ? ws.data() : nullptr, &mf, &wc, 1, nullptr);
+    need(e == hipSuccess, "launch failed (shape not compiled into this build?)");
+    std::fprintf(stderr, "wavesim: closed loop, %s, %lld trajectories x %lld steps\n", tmpc::kernel_name(lay.ks), static_cast<long long>(B), static_cast<long long>(T));
+    FILE *o = std::fopen(argv[4], "wb");
+    need(o != nullptr, "cannot open output file");
+    need(std::fwrite(err2.data(), 8, b, o) == b && std::fwrite(x.data(), 8, b * nx, o) == b * nx && std::fwrite(cons.data(), 8, b, o) == b &&
+         std::fwrite(tube.data(), 4, b, o) == b && std::fwrite(nopt.data(), 4, b, o) == b && std::fwrite(itsum.data(), 4, b, o) == b, "short write");
+    const uint64_t nr = tmpc::sim_rendezvous_count();
+    std::fwrite(&nr, 8, 1, o);
+    std::fclose(o);
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::string(argv[1]) == "--loop") return run_loop(argc, argv);
     need(argc == 4 || argc == 5, "usage: wavesim <layout> [<layout variant 1>] <batch> <out>");
     const int nvar = argc - 3;
     Layout lay[2];
