@@ -499,9 +499,9 @@ int ensure_staging(tmpc_handle *h, int64_t B) {
     return TMPC_OK;
 }
 
-int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
-            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int32_t *const *ws = nullptr,
-            bool variants_valid = false) {
+// The next pair of timing events of the handle's pool (tmpc_last_kernel_ms / tmpc_kernel_ms_total read them); records the first one.
+// Beyond 4096 pairs the last one is reused.
+int begin_timed_launch(tmpc_handle *h) {
     hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
     if (h->pool_used < 4096) {
         if (h->pool_used == h->pool.size()) {
@@ -516,6 +516,13 @@ int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, con
     }
     h->ev0 = e0; h->ev1 = e1;
     HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    return TMPC_OK;
+}
+
+int enqueue(tmpc_handle *h, int64_t B, const double *x_k, const double *ref, const uint8_t *variant, double *u_nom,
+            double *x_nom0, double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, int32_t *const *ws = nullptr,
+            bool variants_valid = false) {
+    { const int rce = begin_timed_launch(h); if (rce) return rce; }
     if (variant != nullptr && !variants_valid)      // (the closed loop's selector is its own gamma flags: always 0 or 1)
         HIP_TRY(h, tmpc::launch_mark_invalid_variants(variant, h->nvariants, B, h->nx, h->nu, h->N, u_nom, x_nom0, xu_ss, x_nom, status,
                                                       iters, h->stream));
@@ -1170,20 +1177,7 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             // (Measured and dropped: the two launches of a step on two streams, so that the second one's workgroups start on the CUs the
             // first one's tail leaves idle -- config 4 extended 0.27 -> 0.28 s: the fork / join events of every step cost more.)
             for (int t = 0; t < T; ++t) {
-                hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
-                if (h->pool_used < 4096) {
-                    if (h->pool_used == h->pool.size()) {
-                        hipEvent_t a = nullptr, b2 = nullptr;
-                        HIP_TRY(h, hipEventCreate(&a));
-                        HIP_TRY(h, hipEventCreate(&b2));
-                        h->pool.emplace_back(a, b2);
-                    }
-                    e0 = h->pool[h->pool_used].first;
-                    e1 = h->pool[h->pool_used].second;
-                    ++h->pool_used;
-                }
-                h->ev0 = e0; h->ev1 = e1;
-                HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+                if ((r2 = begin_timed_launch(h))) return r2;
                 for (int k = 0; k < 2; ++k)
                     HIP_TRY(h, tmpc::launch_solve_mc_step(h->v[k].d, h->v[k].shape, k, B, gam[t & 1], h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, ws[k],
                                                           d_mf, t, gam[(t + 1) & 1], &h->wc, h->n_cu, h->stream));
@@ -1200,20 +1194,7 @@ int mc_run_impl(tmpc_handle *h, int64_t B, int32_t T, int extended, const double
             mf.m = m; mf.st = st; mf.T = T;
             const tmpc::McFused *d_mf = nullptr;            // the record itself lives in the arena: the kernel reads it field by field
             if ((r2 = up(&mf, sizeof(mf), reinterpret_cast<const void **>(&d_mf)))) return r2;
-            hipEvent_t e0 = h->pool.back().first, e1 = h->pool.back().second;
-            if (h->pool_used < 4096) {                      // (the launch counts in tmpc_kernel_ms_total like any solve launch)
-                if (h->pool_used == h->pool.size()) {
-                    hipEvent_t a = nullptr, b2 = nullptr;
-                    HIP_TRY(h, hipEventCreate(&a));
-                    HIP_TRY(h, hipEventCreate(&b2));
-                    h->pool.emplace_back(a, b2);
-                }
-                e0 = h->pool[h->pool_used].first;
-                e1 = h->pool[h->pool_used].second;
-                ++h->pool_used;
-            }
-            h->ev0 = e0; h->ev1 = e1;
-            HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+            if ((r2 = begin_timed_launch(h))) return r2;          // (the launch counts in tmpc_kernel_ms_total like any solve launch)
             HIP_TRY(h, tmpc::launch_solve_mc(v.d, v.shape, B, h->d_u, h->d_x0, h->d_ss, h->d_st, h->d_it, ws[0], d_mf, &h->wc, h->n_cu, h->stream));
             HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
             h->timed = true;
