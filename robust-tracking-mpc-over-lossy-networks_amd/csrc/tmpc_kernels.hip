@@ -517,7 +517,9 @@ __device__ __forceinline__ void solve_body(
     for (;;) {
         int64_t b;
         if (first_item) {
-            b = static_cast<int64_t>(blockIdx.x) * WPB + wave;
+            // (wave-major: wave w of workgroup k takes item w * gridDim.x + k, so that a batch smaller than the card's resident waves
+            // spreads over the CUs -- one wave per SIMD, or per CU -- instead of filling a few CUs with two waves per SIMD)
+            b = static_cast<int64_t>(wave) * gridDim.x + blockIdx.x;
             first_item = false;
         } else {
             // a plain look first: at the end of the launch every wave would otherwise add one failing draw to a burst of
@@ -1665,7 +1667,7 @@ hipError_t launch_wpb(const DeviceQP &qp, int variant_id, int64_t B, const doubl
             if (dev_id >= 0 && dev_id < 64) attr_lds[dev_id] = lds;
         }
     }
-    int64_t blocks = (B + WPB - 1) / WPB;
+    int64_t blocks = B;                                      // (capped at one workgroup per CU below; the first items are dealt wave-major)
     // one persistent workgroup per CU (the LDS footprint admits no second one): the model is staged once and every wave
     // fetches its next instance as soon as it is done with the current one (grid-stride over the batch)
     const int64_t cap = static_cast<int64_t>(n_cu);

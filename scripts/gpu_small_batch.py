@@ -5,6 +5,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import numpy as np
 import common
 from LinearMPCOverNetworks import _native
+if os.environ.get("TMPC_LIB"):
+    _native.LIB_PATH = os.path.abspath(os.environ["TMPC_LIB"])
 S = np.load(os.path.join(common.GOLDEN, "cartpole_N10_states.npy"))
 rng = np.random.default_rng(0)
 for N, ext in ((10, False), (20, False), (20, True)):
