@@ -1608,7 +1608,9 @@ constexpr int design_rows() { return (DP + DS) * WAVE <= 64 ? (DP + DS) * WAVE :
 template <int NV, int DP, int DS, int KC, int CP, int CS>
 constexpr int waves_per_block() {
     constexpr int gr = design_rows<DP, DS>();
-    if (NV <= 12 && kernel_lds_bytes<Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, 8)>>(8, gr) <= 160 * 1024) return 8;
+    // (twelve variables with four slots of single rows sit AT the 256-register cap of two waves per SIMD -- any change of the kernel tipped that
+    // shape into scratch -- and take one wave per SIMD like the sixteen-variable shapes)
+    if (NV <= 12 && !(NV > 8 && DS >= 4) && kernel_lds_bytes<Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, 8)>>(8, gr) <= 160 * 1024) return 8;
     using SH = Shape<NV, DP, DS, KC, CP, CS, tile_rows(NV, 4)>;
     return kernel_lds_bytes<SH>(4, gr) <= 160 * 1024 ? 4 : (kernel_lds_bytes<SH>(3, gr) <= 160 * 1024 ? 3 : 2);
 }
@@ -1706,7 +1708,11 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
 // (config 1); the paired + factored shapes cover the cartpole: base problem at N <= 11 (bench) and N <= 23 (the reference's
 // N = 20; terminal block of 420 rows = 210 functionals of width 5), packet-received problem at N <= 11 and N <= 23
 // (initial-state block Z (-) W of 854 rows = 427 functionals of width 4).
-#if defined(TMPC_ONLY_BENCH)
+#if defined(TMPC_ONE_SHAPE)
+// developer builds: one shape, e.g. -DTMPC_ONE_SHAPE="12,0,4,0,0,0" (register notes of a single instantiation in seconds)
+#define TMPC_APPLY(X, ...) X(__VA_ARGS__)
+#define TMPC_SHAPES(X) TMPC_APPLY(X, TMPC_ONE_SHAPE)
+#elif defined(TMPC_ONLY_BENCH)
 #define TMPC_SHAPES(X) X(11, 1, 0, 5, 4, 0)
 #elif defined(TMPC_SIM_SHAPES_N20)
 // tests/wavesim, developer builds: the two shapes of the cart-pole at the reference's horizon N = 20

@@ -32,8 +32,7 @@ def test_wave_shapes_have_no_private_segment():
 
 def test_fused_closed_loop_kernels_match_the_solve_kernels():
     """closed_loop_kernel<shape> is solve_kernel<shape>'s body with the trajectory's state machines between two solves (the record of
-    the loop read through the constant address space, field by field): the same register budget, no scratch -- except the one
-    shape whose solve kernel already sits at 256 of 256 registers."""
+    the loop read through the constant address space, field by field): the same register budget, no scratch."""
     ks = _kernels()
     fused = {n: k for n, k in ks.items() if "::closed_loop_kernel<" in n}
     wave = {n.split("::solve_kernel")[1]: k for n, k in ks.items() if "::solve_kernel<" in n}
@@ -43,17 +42,14 @@ def test_fused_closed_loop_kernels_match_the_solve_kernels():
         twin = [v for m, v in wave.items() if m.split("(")[0] == shape]
         assert len(twin) == 1, (n, sorted(wave))
         assert k[".vgpr_count"] <= twin[0][".vgpr_count"] + 24, (n, k[".vgpr_count"], twin[0][".vgpr_count"])
-        limit = 64 if shape.replace(" ", "") == "<12,0,4,0,0,0,8>" else 0
-        assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"])
+        assert k[".private_segment_fixed_size"] == 0, (n, k[".private_segment_fixed_size"])
     bench = [k for n, k in fused.items() if "closed_loop_kernel<11, 1, 0, 5, 4, 0, 8>" in n]
     assert len(bench) == 1 and bench[0][".vgpr_count"] <= 256 and bench[0][".vgpr_spill_count"] == 0
     # the extended controller's form: one problem at one time step, the state machines of its trajectories inside
     step = {n: k for n, k in ks.items() if "::closed_loop_step_kernel<" in n}
     assert len(step) == 13, sorted(step)
     for n, k in step.items():
-        shape = n.split("::closed_loop_step_kernel")[1].split("(")[0]
-        limit = 64 if shape.replace(" ", "") == "<12,0,4,0,0,0,8>" else 0
-        assert k[".private_segment_fixed_size"] <= limit, (n, k[".private_segment_fixed_size"])
+        assert k[".private_segment_fixed_size"] == 0, (n, k[".private_segment_fixed_size"])
 
 
 def test_other_kernels_stay_within_their_known_footprint():
