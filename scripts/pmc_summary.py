@@ -21,6 +21,9 @@ for d in sys.argv[2:]:
             name = r["Kernel_Name"].split("(tmpc::DeviceQP")[0].replace("void ", "").replace("(anonymous namespace)::", "")
             acc[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
         for k, v in acc.items():
+            # (smaller batches have the full grid as well since the first work items are dealt wave-major: a full-size dispatch is one whose
+            # counter is within a factor of two of the largest -- every counter collected here grows with the work of a launch)
+            v = [x for x in v if 2 * x >= max(v)] if max(v) > 0 else v
             res[k] = (sum(v) / len(v), len(v))
 last = None
 for (name, ctr), (v, n) in res.items():
