@@ -519,7 +519,9 @@ __device__ __forceinline__ void solve_body(
         if (first_item) {
             // (wave-major: wave w of workgroup k takes item w * gridDim.x + k, so that a batch smaller than the card's resident waves
             // spreads over the CUs -- one wave per SIMD, or per CU -- instead of filling a few CUs with two waves per SIMD)
-            b = static_cast<int64_t>(wave) * gridDim.x + blockIdx.x;
+            // -- and block-major for a full batch: the eight instances of a workgroup are then neighbours in the output arrays (wave-major
+            // throughout cost 0.4 MB more HBM traffic per launch of 4096)
+            b = B < n_waves ? static_cast<int64_t>(wave) * gridDim.x + blockIdx.x : static_cast<int64_t>(blockIdx.x) * WPB + wave;
             first_item = false;
         } else {
             // a plain look first: at the end of the launch every wave would otherwise add one failing draw to a burst of
