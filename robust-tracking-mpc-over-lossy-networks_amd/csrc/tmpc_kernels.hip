@@ -1719,6 +1719,9 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
 #elif defined(TMPC_SIM_SHAPES_N20)
 // tests/wavesim, developer builds: the two shapes of the cart-pole at the reference's horizon N = 20
 #define TMPC_SHAPES(X) X(22, 2, 0, 5, 4, 0) X(26, 2, 0, 4, 7, 0)
+#elif defined(TMPC_SIM_SHAPES_EXT)
+// tests/wavesim: the two problems of the extended controller at N = 10 (the closed loop with a launch per problem and step)
+#define TMPC_SHAPES(X) X(11, 1, 0, 5, 4, 0) X(15, 1, 0, 4, 7, 0)
 #elif defined(TMPC_SIM_SHAPES)
 // tests/wavesim: the bench shape (paired + factored functionals) and the shape of BASELINE config 1 (all rows dense and single)
 #define TMPC_SHAPES(X) X(11, 1, 0, 5, 4, 0) X(8, 0, 2, 0, 0, 0)
@@ -1747,6 +1750,9 @@ hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &s, int va
 // tmpc_fused.hip: this translation unit holds the FUSED = 1 instantiations and nothing else (compiled next to the main one)
 hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, double *u_nom, double *x_nom0, double *xu_ss,
                            int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, WorkCounter *wc, int n_cu, hipStream_t stream) {
+#if defined(TMPC_HOST_SIM) && defined(TMPC_SIM_SHAPES_EXT)
+    return hipErrorInvalidValue;       // (tests/wavesim: the binary of the extended controller instantiates closed_loop_step_kernel only)
+#else
 #define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
         return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>(), 1>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, \
@@ -1754,6 +1760,7 @@ hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, 
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE
     return hipErrorInvalidValue;
+#endif
 }
 #endif
 #if defined(TMPC_HOST_SIM) || !defined(TMPC_FUSED_TU)
@@ -1819,6 +1826,9 @@ hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id
                         const double *x_k, const double *ref, const uint8_t *variant, double *u_nom, double *x_nom0,
                         double *xu_ss, double *x_nom, int32_t *status, int32_t *iters, const int32_t *ws_in, int32_t *ws_out,
                         WorkCounter *wc, int n_cu, hipStream_t stream) {
+#if defined(TMPC_HOST_SIM) && defined(TMPC_SIM_SHAPES_EXT)
+    return hipErrorInvalidValue;
+#else
 #define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
         return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>()>(qp, variant_id, B, x_k, ref, variant, u_nom, x_nom0, \
@@ -1826,6 +1836,7 @@ hipError_t launch_solve(const DeviceQP &qp, const KernelShape &s, int variant_id
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE
     return hipErrorInvalidValue;
+#endif
 }
 
 #endif      // main translation unit

@@ -158,6 +158,39 @@ def test_fused_closed_loop_source_under_sanitizers(binaries, cartpole, oracle_li
     assert np.array_equal(outs[0]["iters_sum"], outs[2]["iters_sum"])
 
 
+def test_extended_closed_loop_source_under_sanitizers(binaries, oracle_lib):
+    """closed_loop_step_kernel -- the extended controller's form: per time step one launch per problem (base / packet-received), each QP
+    followed by its trajectory's state machines, the arrival flags in two alternating buffers (csrc/tmpc_api.cpp: mc_run_impl; the harness
+    steps the two launches the same way) -- on the host execution model under ASan + UBSan, warm-started: equal to the numpy state
+    machines (RobustEstimator, ConsistentActuator with x_nom_0 adoption) driven by the ORACLE's solves of
+    results_linear_system_with_extendedMPC.py:247-378."""
+    from LinearMPCOverNetworks import montecarlo
+    from oracle.oracle import Oracle
+    nb, T = 8, 8
+    mpc, w = common.make_mpc("cartpole", 10, True, extended=True)
+    d = mpc._problem_dict()
+    p_loss = np.tile([0.0, 0.3, 0.6, 0.9], nb // 4)
+    th, ga, dist = montecarlo.draw_realisations(nb, T, w["w_bound"], seed=9)
+    ref = np.where(np.arange(T) < 4, 0.5, -0.3)
+    K, Kp = mpc.get_steady_state_controller_gain(), mpc.get_ancillary_controller_gain()
+    orc = Oracle(d)
+    seen = []
+
+    def packets(x_hat, r, gamma=None):
+        seen.append(np.array(gamma))
+        sol = orc.solve(x_hat, r, gamma)
+        u_ss = sol["u_ss"] + sol["x_ss"] @ mpc._K.T
+        return np.ascontiguousarray(np.concatenate([sol["u_nom"], u_ss[:, None, :]], axis=1).transpose(0, 2, 1)), sol["x_nom0"], sol["status"]
+    host = montecarlo.run_remote_tube_mpc(packets, w["A"], w["B"], K, Kp, 10, mpc._Z, p_loss, ref, th, ga, dist, extended=True)
+    assert {0, 1} <= set(np.concatenate(seen).tolist())                    # both problems are in use
+    o = run_case.run_loop(binaries["wavesim_ext_asan"], d, K, Kp, mpc._Z, p_loss, ref, th, ga, dist, warm=True, extended=True, env=SAN_ENV)
+    assert_clean(o)
+    np.testing.assert_allclose(o["x_final"], host["x_final"], atol=1e-8, rtol=0)
+    np.testing.assert_allclose(o["tracking_error"], host["tracking_error"], atol=1e-10, rtol=0)
+    assert np.array_equal(o["tube_violations"], host["tube_violations"]) and np.all(o["tube_violations"] == 0)
+    assert np.array_equal(o["not_optimal"], host["not_optimal"])
+
+
 @pytest.fixture(scope="module")
 def block_binaries():
     return _build_or_skip()

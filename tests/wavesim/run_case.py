@@ -15,7 +15,7 @@ BUILD = os.path.join(HERE, "_build")
 def build_all(extra="-DTMPC_SIM_SHAPES"):
     """every binary of the Makefile in one parallel make (what __graft_entry__.build() runs as well); up to date -> no-op"""
     subprocess.check_call(["make", "-s", "-j6", "-C", HERE, "all", f"EXTRA={extra}"])
-    return {t: os.path.join(BUILD, t) for t in ("wavesim", "wavesim_asan", "wavesim_msan", "blocksim", "blocksim_asan", "blocksim_msan",
+    return {t: os.path.join(BUILD, t) for t in ("wavesim", "wavesim_asan", "wavesim_msan", "wavesim_ext_asan", "blocksim", "blocksim_asan", "blocksim_msan",
                                                  "lpsim_asan", "lpsim_msan")}
 
 
@@ -101,19 +101,23 @@ def run_lp(binary, H, h, Cmat, relax=None, relax_by=1.0, env=None, timeout=1800)
     return dict(val=val, x=x, status=st, iters=it, stderr=res.stderr, stdout=res.stdout)
 
 
-def run_loop(binary, d, K, K_anc, Z, p_loss, ref, th_u, ga_u, w, x0=None, smart=False, warm=False, env=None, timeout=3600):
-    """the FUSED closed loop (wavesim --loop: closed_loop_kernel, a wave keeps its trajectory for all T steps) for the plain controller
-    of problem dict `d`; gains K, K_anc (nu, nx), tube cross-section Z (object with .A, .b) or None"""
+def run_loop(binary, d, K, K_anc, Z, p_loss, ref, th_u, ga_u, w, x0=None, smart=False, warm=False, env=None, timeout=3600, extended=False):
+    """the closed loop with the state machines inside the solve kernels (wavesim --loop) for the controller of problem dict `d`: plain ->
+    closed_loop_kernel, a wave keeps its trajectory for all T steps; extended (d carries the packet-received problem) -> one
+    closed_loop_step_kernel launch per problem and time step.  Gains K, K_anc (nu, nx), tube cross-section Z (object with .A, .b) or None"""
     from LinearMPCOverNetworks import _native
     L = _native.lib()
     L.tmpc_debug_dump_layout.argtypes = [C.c_void_p, C.c_int, C.c_char_p]
     h = _native.create(d, -1)
     try:
         with tempfile.TemporaryDirectory() as tmp:
-            lay, loop, out = (os.path.join(tmp, n) for n in ("layout.bin", "loop.bin", "out.bin"))
-            rc = L.tmpc_debug_dump_layout(h.ptr, 0, lay.encode())
-            if rc != 0:
-                raise RuntimeError(f"tmpc_debug_dump_layout failed: {rc}")
+            loop, out = (os.path.join(tmp, n) for n in ("loop.bin", "out.bin"))
+            lays = []
+            for k in range(2 if extended else 1):
+                lays.append(os.path.join(tmp, f"layout{k}.bin"))
+                rc = L.tmpc_debug_dump_layout(h.ptr, k, lays[-1].encode())
+                if rc != 0:
+                    raise RuntimeError(f"tmpc_debug_dump_layout({k}) failed: {rc}")
             c = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64))
             th_u, ga_u, w = c(th_u), c(ga_u), c(w)
             B, T = th_u.shape
@@ -121,11 +125,11 @@ def run_loop(binary, d, K, K_anc, Z, p_loss, ref, th_u, ga_u, w, x0=None, smart=
             HZ = np.zeros((0, nx)) if Z is None else c(Z.A)
             hZ = np.zeros(0) if Z is None else c(Z.b)
             with open(loop, "wb") as f:
-                np.array([B, T, nx, nu, HZ.shape[0], 0, int(bool(smart)), int(bool(warm))], dtype=np.int64).tofile(f)
+                np.array([B, T, nx, nu, HZ.shape[0], int(bool(extended)), int(bool(smart)), int(bool(warm))], dtype=np.int64).tofile(f)
                 for a in (np.asarray(d["A"]), np.asarray(d["B"]), K, K_anc, HZ, hZ, p_loss, ref, th_u, ga_u, w,
                           np.zeros((B, nx)) if x0 is None else x0):
                     c(a).tofile(f)
-            res = subprocess.run([binary, "--loop", lay, loop, out], capture_output=True, text=True, timeout=timeout,
+            res = subprocess.run([binary, "--loop"] + lays + [loop, out], capture_output=True, text=True, timeout=timeout,
                                  env=dict(os.environ, **(env or {})))
             if res.returncode != 0:
                 raise RuntimeError(f"{os.path.basename(binary)} --loop failed ({res.returncode}):\n{res.stderr[-8000:]}")

@@ -6,9 +6,10 @@
 // product: every byte it reads is either that file or the batch.
 //
 //   wavesim <layout file> [<layout file of variant 1>] <batch file> <output file>
-//   wavesim --loop <layout file> <loop file> <output file>      the FUSED closed loop (closed_loop_kernel: a wave keeps its trajectory
-//                                                               for all T steps, the state machines of tmpc_mc_step.hpp between two solves)
-// loop file  : int64 B, T, nx, nu, rZ, extended(0), smart, warm; doubles A [nx][nx], B [nx][nu], K [nu][nx], K_anc [nu][nx], HZ [rZ][nx], hZ [rZ],
+//   wavesim --loop <layout file> [<layout of variant 1>] <loop file> <output file>
+//              the closed loop with the state machines of tmpc_mc_step.hpp INSIDE the solve kernels: one layout = closed_loop_kernel (a wave keeps
+//              its trajectory for all T steps); two layouts = the extended controller, closed_loop_step_kernel per problem and time step
+// loop file  : int64 B, T, nx, nu, rZ, extended, smart, warm; doubles A [nx][nx], B [nx][nu], K [nu][nx], K_anc [nu][nx], HZ [rZ][nx], hZ [rZ],
 //              p_loss [B], ref [T], th_u [B][T], ga_u [B][T], w [B][T][nx], x0 [B][nx]
 // its output : err2 [B] doubles, x_final [B][nx], consistent [B]; tube_viol [B], not_optimal [B], iters_sum [B] int32; one uint64 (rendezvous)
 // layout file: include/tmpc.h, tmpc_debug_dump_layout
@@ -71,15 +72,17 @@ void read_layout(const char *path, Layout &L) {
 // The arrays of tmpc::McState as the host side of tmpc_mc_run lays them out (tmpc_api.cpp: mc_run_impl), every one a heap block of its
 // exact size; what the kernel must initialise itself stays poisoned for MemorySanitizer.
 int run_loop(int argc, char **argv) {
-    need(argc == 5, "usage: wavesim --loop <layout> <loop file> <out>");
-    Layout lay;
-    read_layout(argv[2], lay);
-    FILE *f = std::fopen(argv[3], "rb");
+    need(argc == 5 || argc == 6, "usage: wavesim --loop <layout> [<layout of the packet-received problem>] <loop file> <out>");
+    const int nvar = argc - 4;
+    Layout lays[2];
+    for (int k = 0; k < nvar; ++k) read_layout(argv[2 + k], lays[k]);
+    Layout &lay = lays[0];
+    FILE *f = std::fopen(argv[2 + nvar], "rb");
     need(f != nullptr, "cannot open loop file");
     int64_t hd[8];
     need(std::fread(hd, 8, 8, f) == 8, "short loop file");
     const int64_t B = hd[0], T = hd[1], nx = hd[2], nu = hd[3], rZ = hd[4];
-    need(nx == lay.d.nx && nu == lay.d.nu && hd[5] == 0 && B > 0 && T > 0, "loop file does not belong to this layout (plain controller only)");
+    need(nx == lay.d.nx && nu == lay.d.nu && hd[5] == (nvar == 2 ? 1 : 0) && B > 0 && T > 0, "loop file does not belong to these layouts");
     const int N = lay.d.N;
     auto rd = [&](size_t n) { std::vector<double> v(n); need(n == 0 || std::fread(v.data(), 8, n, f) == n, "short loop file"); return v; };
     const size_t b = static_cast<size_t>(B), t_ = static_cast<size_t>(T);
@@ -89,7 +92,7 @@ int run_loop(int argc, char **argv) {
     tmpc::McFused mf{};
     tmpc::McModel &m = mf.m;
     tmpc::McState &st = mf.st;
-    m.nx = static_cast<int>(nx); m.nu = static_cast<int>(nu); m.N = N; m.extended = 0; m.rZ = static_cast<int>(rZ);
+    m.nx = static_cast<int>(nx); m.nu = static_cast<int>(nu); m.N = N; m.extended = nvar == 2 ? 1 : 0; m.rZ = static_cast<int>(rZ);
     m.plant = TMPC_PLANT_LINEAR; m.substeps = 1; m.smart = static_cast<int>(hd[6]);
     m.A = A.data(); m.B = Bm.data(); m.K = K.data(); m.K_anc = Ka.data(); m.HZ = HZ.data(); m.hZ = hZ.data();
     std::vector<double> x(x0), xh(x0), xn(x0), Ub(b * (N + 1) * nu, 0.0), ul0(b * nu, 0.0), xn0l(b * nx, 0.0), refk(b * nx, 0.0), err2(b, 0.0), cons(b, 0.0);
@@ -108,12 +111,28 @@ int run_loop(int argc, char **argv) {
     // outputs of the solve inside the loop: uninitialised on purpose
     std::unique_ptr<double[]> u(new double[b * N * nu]), xo(new double[b * nx]), ss(new double[b * (nx + nu)]);
     std::unique_ptr<int32_t[]> sst(new int32_t[b]), it(new int32_t[b]);
-    std::vector<int32_t> ws(hd[7] ? b * tmpc::WS_STRIDE : 0, 0);
+    std::vector<int32_t> ws(hd[7] ? b * tmpc::WS_STRIDE : 0, 0), ws1(hd[7] && nvar == 2 ? b * tmpc::WS_STRIDE : 0, 0);
     tmpc::WorkCounter wc;
-    const hipError_t e = tmpc::launch_solve_mc(lay.d, lay.ks, B, u.get(), xo.get(), ss.get(), sst.get(), it.get(), hd[7] ? ws.data() : nullptr, &mf, &wc, 1, nullptr);
-    need(e == hipSuccess, "launch failed (shape not compiled into this build?)");
-    std::fprintf(stderr, "wavesim: closed loop, %s, %lld trajectories x %lld steps\n", tmpc::kernel_name(lay.ks), static_cast<long long>(B), static_cast<long long>(T));
-    FILE *o = std::fopen(argv[4], "wb");
+    if (nvar == 1) {
+        // one problem: closed_loop_kernel, a wave per trajectory for all T steps
+        const hipError_t e = tmpc::launch_solve_mc(lay.d, lay.ks, B, u.get(), xo.get(), ss.get(), sst.get(), it.get(), hd[7] ? ws.data() : nullptr, &mf, &wc, 1, nullptr);
+        need(e == hipSuccess, "launch failed (shape not compiled into this build?)");
+    } else {
+        // the extended controller (tmpc_api.cpp: mc_run_impl): per time step one closed_loop_step_kernel launch per problem; the arrival
+        // flags a step writes select the problem of the NEXT step, so the selector read and the flags written alternate between two buffers
+        std::vector<uint8_t> gam2(b, 1);
+        uint8_t *gam_buf[2] = {gam.data(), gam2.data()};
+        for (int t = 0; t < static_cast<int>(T); ++t)
+            for (int k = 0; k < 2; ++k) {
+                int32_t *wsk = !hd[7] ? nullptr : (k == 0 ? ws.data() : ws1.data());
+                const hipError_t e = tmpc::launch_solve_mc_step(lays[k].d, lays[k].ks, k, B, gam_buf[t & 1], u.get(), xo.get(), ss.get(), sst.get(), it.get(), wsk,
+                                                                &mf, t, gam_buf[(t + 1) & 1], &wc, 1, nullptr);
+                need(e == hipSuccess, "launch failed (shape not compiled into this build?)");
+            }
+    }
+    std::fprintf(stderr, "wavesim: closed loop, %s%s, %lld trajectories x %lld steps\n", tmpc::kernel_name(lay.ks), nvar == 2 ? " + packet-received problem" : "",
+                 static_cast<long long>(B), static_cast<long long>(T));
+    FILE *o = std::fopen(argv[3 + nvar], "wb");
     need(o != nullptr, "cannot open output file");
     need(std::fwrite(err2.data(), 8, b, o) == b && std::fwrite(x.data(), 8, b * nx, o) == b * nx && std::fwrite(cons.data(), 8, b, o) == b &&
          std::fwrite(tube.data(), 4, b, o) == b && std::fwrite(nopt.data(), 4, b, o) == b && std::fwrite(itsum.data(), 4, b, o) == b, "short write");
