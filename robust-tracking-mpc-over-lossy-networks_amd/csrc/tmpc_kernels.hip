@@ -1736,6 +1736,11 @@ unsigned long sim_rendezvous_count() { return sim_rendezvous_total; }
 hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &s, int variant_id, int64_t B, const uint8_t *variant, double *u_nom,
                                 double *x_nom0, double *xu_ss, int32_t *status, int32_t *iters, int32_t *ws, const McFused *mc, int t,
                                 uint8_t *gamma_out, WorkCounter *wc, int n_cu, hipStream_t stream) {
+#if defined(TMPC_HOST_SIM) && !defined(TMPC_SIM_SHAPES_EXT)
+    (void)qp; (void)s; (void)variant_id; (void)B; (void)variant; (void)u_nom; (void)x_nom0; (void)xu_ss; (void)status; (void)iters; (void)ws; (void)mc; (void)t;
+    (void)gamma_out; (void)wc; (void)n_cu; (void)stream;
+    return hipErrorInvalidValue;       // (tests/wavesim: only the binary of the extended controller instantiates closed_loop_step_kernel)
+#else
     const McStepArg arg{mc, t, gamma_out};
 #define TMPC_CASE(A, B_, C, D, E, F)                                                                                      \
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
@@ -1744,6 +1749,7 @@ hipError_t launch_solve_mc_step(const DeviceQP &qp, const KernelShape &s, int va
     TMPC_SHAPES(TMPC_CASE)
 #undef TMPC_CASE
     return hipErrorInvalidValue;
+#endif
 }
 #endif
 #if defined(TMPC_HOST_SIM) || (defined(TMPC_FUSED_TU) && TMPC_FUSED_TU == 1)
@@ -1757,7 +1763,11 @@ hipError_t launch_solve_mc(const DeviceQP &qp, const KernelShape &s, int64_t B, 
     if (s.nvp == A && s.dp == B_ && s.ds == C && s.kcp == D && s.cp == E && s.cs == F)                                    \
         return launch_wpb<A, B_, C, D, E, F, waves_per_block<A, B_, C, D, E, F>(), 1>(qp, 0, B, nullptr, nullptr, nullptr, u_nom, x_nom0, \
                                                                                          xu_ss, nullptr, status, iters, ws, ws, wc, n_cu, stream, mc);
+#if defined(TMPC_HOST_SIM) && defined(TMPC_SIM_SHAPES)
+    TMPC_CASE(11, 1, 0, 5, 4, 0)       // (tests/wavesim: the fused loop is run on the bench shape; one instantiation less per binary)
+#else
     TMPC_SHAPES(TMPC_CASE)
+#endif
 #undef TMPC_CASE
     return hipErrorInvalidValue;
 #endif

@@ -14,7 +14,7 @@ BUILD = os.path.join(HERE, "_build")
 
 def build_all(extra="-DTMPC_SIM_SHAPES"):
     """every binary of the Makefile in one parallel make (what __graft_entry__.build() runs as well); up to date -> no-op"""
-    subprocess.check_call(["make", "-s", "-j6", "-C", HERE, "all", f"EXTRA={extra}"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", HERE, "all", f"EXTRA={extra}"])
     return {t: os.path.join(BUILD, t) for t in ("wavesim", "wavesim_asan", "wavesim_msan", "wavesim_ext_asan", "blocksim", "blocksim_asan", "blocksim_msan",
                                                  "lpsim_asan", "lpsim_msan")}
 
